@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the BUILD container only).
+
+Two kinds of data are written, both plain ``.npz`` (numeric arrays + strings):
+
+1. ``fixture_<name>.npz`` - the reference's own example fixtures
+   (``/root/reference/examples/*/pkl_input/*.input.pkl`` and the matching
+   ``pkl_output/*.res.pkl``) transcribed to arrays.  The pickles are decoded with
+   ``scape_amd.safe_pickle`` (a symbolic reader that imports/calls nothing named
+   by the file); nothing is unpickled.
+2. ``trace_<name>.npz`` - outputs of the reference's own Python code
+   (``/root/reference/src/scape/apa_core.py`` + ``taichi_core.py``) run here on
+   those inputs and on small synthetic UTRs, with every ``em_algo`` call's
+   inputs/outputs recorded.  ``taichi`` / ``tomllib`` / ``tomli_w`` are not
+   installed in this image, so in-memory stand-in modules are registered first:
+   ``ti.kernel`` / ``ti.func`` become identity decorators and ``tm.log/exp/sqrt``
+   numpy f64 functions, i.e. the reference's kernel *source* executes as ordinary
+   Python on numpy arrays (same f64 arithmetic, serial order).  What that does
+   not pin: Taichi-backend effects below an ulp (libdevice exp/log, the parallel
+   reduction order of ``call_logp_theta_sum_kernel``).
+
+Nothing is written under /root/reference (``sys.dont_write_bytecode``), and the
+reference never travels: only the ``.npz`` files do.
+
+Usage: python tests/golden/make_golden.py [fixtures|traces|synth|all] [names...]
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+import time
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from scape_amd.safe_pickle import load_all  # noqa: E402
+
+FIXTURE_FILES = {
+    "toy": ("examples/toy-example/pkl_input/example.100.1.1.input.pkl",
+            "examples/toy-example/pkl_output/example.100.1.1.res.pkl"),
+    "chr17": ("examples/SCZ-nowa-scape/pkl_input/chr17_merge.100.1.1.input.pkl",
+              "examples/SCZ-nowa-scape/pkl_output/chr17_merge.100.1.1.res.pkl"),
+    "chr19": ("examples/SCZ-nowa-scape/pkl_input/chr19_merge.100.1.1.input.pkl",
+              "examples/SCZ-nowa-scape/pkl_output/chr19_merge.100.1.1.res.pkl"),
+}
+
+# defaults written by prepare_input (reference src/scape/input_processor.py:97-112)
+DEFAULT_PARAMS = dict(n_max_apa=5, n_min_apa=1, min_LA=20, max_LA=150, mu_f=300, sigma_f=50,
+                      min_pa_gap=100, max_beta=70, theta_step=9, beta_step=5, min_ws=0.05,
+                      max_unif_ws=0.15, re_run_mode=True, fixed_run_mode=False,
+                      pre_para_pkl_file=None)
+
+
+# ---------------------------------------------------------------- fixtures
+def write_fixtures():
+    for name, (fin, fout) in FIXTURE_FILES.items():
+        ins = load_all(os.path.join(REF, fin))
+        outs = load_all(os.path.join(REF, fout))
+        assert len(ins) == len(outs)
+        d = {"n_utr": np.int64(len(ins))}
+        for i, ((gene, df), p) in enumerate(zip(ins, outs)):
+            assert p.gene_info_str == gene
+            d[f"u{i}_gene_info_str"] = np.array(gene)
+            for c in ["x", "l", "r", "pa", "cb_id", "read_id"]:
+                d[f"u{i}_{c}"] = np.asarray(df[c])
+            d[f"u{i}_gold_K"] = np.int64(p.K)
+            d[f"u{i}_gold_L"] = np.int64(p.L)
+            d[f"u{i}_gold_alpha_arr"] = np.asarray(p.alpha_arr)
+            d[f"u{i}_gold_beta_arr"] = np.asarray(p.beta_arr)
+            d[f"u{i}_gold_ws"] = np.asarray(p.ws)
+            d[f"u{i}_gold_bic"] = np.float64(p.bic)
+            d[f"u{i}_gold_lb_arr"] = np.asarray(p.lb_arr, dtype=np.float64)
+            d[f"u{i}_gold_label_arr"] = np.asarray(p.label_arr)
+            d[f"u{i}_gold_cb_id_arr"] = np.asarray(p.cb_id_arr)
+            d[f"u{i}_gold_readID_arr"] = np.asarray(p.readID_arr)
+            d[f"u{i}_gold_title"] = np.array(p.title)
+        path = os.path.join(HERE, f"fixture_{name}.npz")
+        np.savez_compressed(path, **d)
+        print("wrote", path, os.path.getsize(path))
+
+
+# ---------------------------------------------------------------- reference loader
+def load_reference():
+    """Import scape.apa_core / scape.taichi_core from /root/reference/src with stand-ins."""
+    if "scape.apa_core" in sys.modules:
+        return sys.modules["scape.apa_core"], sys.modules["scape.taichi_core"]
+
+    ti = types.ModuleType("taichi")
+    tm = types.ModuleType("taichi.math")
+
+    def _ident(f=None, **_kw):
+        return f if f is not None else (lambda g: g)
+
+    ti.kernel = _ident
+    ti.func = _ident
+    ti.cuda, ti.cpu, ti.f64, ti.f32 = "cuda", "cpu", float, float
+    ti.init = lambda *a, **k: None
+    ti.cfg = types.SimpleNamespace(arch="cpu")
+    ti.loop_config = lambda *a, **k: None
+    ti.types = types.SimpleNamespace(ndarray=lambda *a, **k: None)
+    with np.errstate(all="ignore"):
+        pass
+    tm.log = lambda v: np.log(np.float64(v))
+    tm.exp = lambda v: np.exp(np.float64(v))
+    tm.sqrt = lambda v: np.sqrt(np.float64(v))
+    ti.math = tm
+    sys.modules["taichi"] = ti
+    sys.modules["taichi.math"] = tm
+
+    if "tomllib" not in sys.modules:
+        try:
+            import tomllib  # noqa: F401
+        except ModuleNotFoundError:
+            import tomli
+            sys.modules["tomllib"] = tomli
+    if "tomli_w" not in sys.modules:
+        try:
+            import tomli_w  # noqa: F401
+        except ModuleNotFoundError:
+            tw = types.ModuleType("tomli_w")
+
+            def _dump(*a, **k):
+                raise RuntimeError("tomli_w stand-in: not used by the golden generator")
+            tw.dump = _dump
+            sys.modules["tomli_w"] = tw
+
+    import matplotlib
+    matplotlib.use("Agg")
+
+    pkg = types.ModuleType("scape")
+    pkg.__path__ = [os.path.join(REF, "src", "scape")]   # namespace: skip __init__ -> cli -> pysam
+    sys.modules["scape"] = pkg
+    import importlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        tc = importlib.import_module("scape.taichi_core")
+        ac = importlib.import_module("scape.apa_core")
+    return ac, tc
+
+
+class Recorder:
+    """Wraps ApaModel.em_algo / gen_k_arr (monkey-patched at run time, files untouched)."""
+
+    def __init__(self, ac):
+        self.ac = ac
+        self.calls = []
+        self._last_k_arr = None
+        self._orig_em = ac.ApaModel.em_algo
+        self._orig_gen = ac.ApaModel.gen_k_arr
+        rec = self
+
+        def gen_k_arr(K, n):
+            out = rec._orig_gen(K, n)
+            rec._last_k_arr = np.array(out, dtype=np.int64)
+            return out
+
+        def em_algo(model, para, fixed_inference_flag=False):
+            c = dict(K=int(para.K), fixed=bool(fixed_inference_flag),
+                     a0=np.array(para.alpha_arr, dtype=np.float64),
+                     b0=np.array(para.beta_arr, dtype=np.float64),
+                     w0=np.array(para.ws, dtype=np.float64))
+            res = rec._orig_em(model, para, fixed_inference_flag=fixed_inference_flag)
+            c.update(k_arr=rec._last_k_arr.copy(),
+                     a1=np.array(res.alpha_arr, dtype=np.float64),
+                     b1=np.array(res.beta_arr, dtype=np.float64),
+                     w1=np.array(res.ws, dtype=np.float64),
+                     bic=float(res.bic), lb=np.array(res.lb_arr, dtype=np.float64))
+            rec.calls.append(c)
+            return res
+
+        ac.ApaModel.gen_k_arr = staticmethod(gen_k_arr)
+        ac.ApaModel.em_algo = em_algo
+
+    def restore(self):
+        self.ac.ApaModel.em_algo = self._orig_em
+        self.ac.ApaModel.gen_k_arr = self._orig_gen
+
+
+def _pack_calls(calls, kmax):
+    n = len(calls)
+    out = dict(call_K=np.array([c["K"] for c in calls], dtype=np.int64),
+               call_fixed=np.array([c["fixed"] for c in calls], dtype=np.int64),
+               call_bic=np.array([c["bic"] for c in calls], dtype=np.float64),
+               call_nlb=np.array([len(c["lb"]) for c in calls], dtype=np.int64))
+    for key, width in (("a0", kmax), ("b0", kmax), ("w0", kmax + 1), ("a1", kmax), ("b1", kmax),
+                       ("w1", kmax + 1), ("k_arr", 50), ("lb", 50)):
+        arr = np.full((n, width), np.nan)
+        for i, c in enumerate(calls):
+            v = np.asarray(c[key], dtype=np.float64)
+            arr[i, :len(v)] = v
+        out["call_" + key] = arr
+    return out
+
+
+def run_reference_file(name, utrs, params, seed=1, tensor_stride=7, keep_full_tensor=False):
+    """Mimic _infer_pa/infer (apa_core.py:107-147, :1104-1137) on a list of (gene, DataFrame)."""
+    ac, _tc = load_reference()
+    rec = Recorder(ac)
+    d = {"n_utr": np.int64(len(utrs)), "seed": np.int64(seed)}
+    for k, v in params.items():
+        if v is not None:
+            d["param_" + k] = np.array(v)
+    try:
+        np.random.seed(seed)
+        for i, (gene, df) in enumerate(utrs):
+            st = np.random.get_state()
+            d[f"u{i}_rng_keys"] = np.array(st[1], dtype=np.uint32)
+            d[f"u{i}_rng_pos"] = np.int64(st[2])
+            rec.calls = []
+            t0 = time.time()
+            kw = dict(params)
+            kw["data"] = df
+            kw["gene_info_str"] = gene
+            with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                res, model = ac.subsample_run(return_model=True, **kw)
+            dt = time.time() - t0
+            print(f"  {name} u{i} {gene}: {dt:.1f}s K={res.K} alpha={res.alpha_arr} "
+                  f"beta={res.beta_arr} ws={res.ws} bic={res.bic} calls={len(rec.calls)}", flush=True)
+            kmax = max(c["K"] for c in rec.calls)
+            d[f"u{i}_gene_info_str"] = np.array(gene)
+            for c in ["x", "l", "r", "pa", "cb_id", "read_id"]:
+                d[f"u{i}_{c}"] = np.asarray(df[c])
+            # binned data and grids
+            d[f"u{i}_bin_x"] = model.x_arr
+            d[f"u{i}_bin_l"] = model.l_arr
+            d[f"u{i}_bin_r"] = model.r_arr
+            d[f"u{i}_bin_pa"] = model.pa_arr
+            d[f"u{i}_bin_cnt"] = np.asarray(model.cnt_arr, dtype=np.int64)
+            d[f"u{i}_bin_idx"] = np.asarray(model.idx_arr, dtype=np.int64)
+            d[f"u{i}_L"] = np.int64(model.L)
+            d[f"u{i}_min_theta"] = np.float64(model.min_theta)
+            d[f"u{i}_all_theta"] = model.all_theta
+            d[f"u{i}_betas"] = model.predef_beta_arr
+            d[f"u{i}_unif_ll"] = np.float64(model.unif_log_lik)
+            d[f"u{i}_cov_y"] = model.coverage_profile[1]
+            d[f"u{i}_A"] = model.loglik_xlr_t_arr
+            M = model.loglik_marginal_tensor
+            if keep_full_tensor:
+                d[f"u{i}_M"] = M
+            else:
+                sel = np.arange(0, M.shape[0], tensor_stride)
+                d[f"u{i}_M_rows"] = sel.astype(np.int64)
+                d[f"u{i}_M_sel"] = M[sel]
+            finite = M > -1e30
+            d[f"u{i}_M_n_sent"] = np.int64((~finite).sum())
+            d[f"u{i}_M_sum_finite"] = np.float64(M[finite].sum())
+            for k, v in _pack_calls(rec.calls, kmax).items():
+                d[f"u{i}_{k}"] = v
+            d[f"u{i}_res_K"] = np.int64(res.K)
+            d[f"u{i}_res_alpha_arr"] = np.asarray(res.alpha_arr)
+            d[f"u{i}_res_beta_arr"] = np.asarray(res.beta_arr)
+            d[f"u{i}_res_ws"] = np.asarray(res.ws)
+            d[f"u{i}_res_bic"] = np.float64(res.bic)
+            d[f"u{i}_res_lb_arr"] = np.asarray(res.lb_arr, dtype=np.float64)
+            d[f"u{i}_res_label_arr"] = np.asarray(res.label_arr)
+            d[f"u{i}_res_title"] = np.array(res.title)
+            d[f"u{i}_ref_seconds"] = np.float64(dt)
+    finally:
+        rec.restore()
+    path = os.path.join(HERE, f"trace_{name}.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path), flush=True)
+
+
+def write_traces(names):
+    for name in names:
+        fin, _ = FIXTURE_FILES[name]
+        utrs = load_all(os.path.join(REF, fin))
+        run_reference_file(name, utrs, DEFAULT_PARAMS, seed=1,
+                           tensor_stride=7 if name != "toy" else 23)
+
+
+# ---------------------------------------------------------------- small synthetic UTRs
+def synth_utr(rng, n_reads, alphas, betas, ws, L, pa_rate=0.05, r_rate=0.0, noise=0.05):
+    """Reads drawn from the model's own generative story."""
+    import pandas as pd
+    alphas, betas, ws = map(np.asarray, (alphas, betas, ws))
+    comp = rng.choice(len(alphas), size=n_reads, p=ws / ws.sum())
+    theta = rng.normal(alphas[comp], betas[comp])
+    s = rng.choice(np.arange(20, 150, 10), size=n_reads)
+    x = np.rint(rng.normal(theta + s - 300, 50))
+    x = np.clip(x, 0, np.maximum(theta - 31, 0))
+    room = np.maximum(theta - x, 31)
+    l = np.floor(31 + rng.random(n_reads) * (np.minimum(132, room) - 31 + 1))
+    l = np.clip(l, 31, 132)
+    is_noise = rng.random(n_reads) < noise
+    x[is_noise] = np.floor(rng.random(is_noise.sum()) * (L - 200))
+    l[is_noise] = rng.integers(31, 133, size=is_noise.sum())
+    pa = np.full(n_reads, np.nan)
+    has_pa = (rng.random(n_reads) < pa_rate) & ~is_noise
+    pa[has_pa] = np.rint(theta[has_pa])
+    r = np.full(n_reads, np.nan)
+    has_r = (rng.random(n_reads) < r_rate) & ~has_pa & ~is_noise
+    r[has_r] = np.minimum(np.floor(rng.random(has_r.sum()) * s[has_r]) + 1, s[has_r])
+    return pd.DataFrame({"x": x.astype(np.int64), "l": l.astype(np.int64), "r": r, "pa": pa,
+                         "cb_id": np.arange(n_reads, dtype=np.int64),
+                         "read_id": np.arange(n_reads, dtype=np.int64)})
+
+
+def write_synth():
+    rng = np.random.default_rng(20240612)
+    # file 1: three UTRs, default K range 3..1 (keeps the python reference to ~1 min)
+    utrs = [
+        ("synA:g1:1:1-2000:+", synth_utr(rng, 260, [700, 1400], [20, 35], [0.6, 0.4], 2000, pa_rate=0.06)),
+        ("synA:g2:1:1-2600:-", synth_utr(rng, 220, [500, 1250, 2100], [15, 30, 45], [0.3, 0.3, 0.4], 2600,
+                                          pa_rate=0.03, r_rate=0.10)),
+        ("synA:g3:1:1-2000:+", synth_utr(rng, 150, [900], [25], [1.0], 2000, pa_rate=0.0, noise=0.15)),
+    ]
+    p = dict(DEFAULT_PARAMS)
+    p["n_max_apa"] = 3
+    run_reference_file("synA", utrs, p, seed=1, keep_full_tensor=True)
+    # file 2: cap hit -> re-run loop (n_max_apa=2 with 3 true sites), non-default grids
+    utrs = [
+        ("synB:g1:1:1-2400:+", synth_utr(rng, 300, [600, 1300, 2000], [20, 20, 30], [0.35, 0.3, 0.35], 2400,
+                                          pa_rate=0.05)),
+        ("synB:g2:1:1-2000:+", synth_utr(rng, 130, [800, 1500], [30, 30], [0.5, 0.5], 2000, pa_rate=0.1,
+                                          r_rate=0.2)),
+    ]
+    p = dict(DEFAULT_PARAMS)
+    p.update(n_max_apa=2, theta_step=11, beta_step=10, max_beta=65, min_pa_gap=80, sigma_f=45, mu_f=290)
+    run_reference_file("synB", utrs, p, seed=7, keep_full_tensor=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    names = sys.argv[2:] or list(FIXTURE_FILES)
+    if what in ("fixtures", "all"):
+        write_fixtures()
+    if what in ("synth", "all"):
+        write_synth()
+    if what in ("traces", "all"):
+        write_traces(names)
