@@ -1,0 +1,19 @@
+"""click group exposing ``infer_pa`` (reference cli.py:7-31 registers six commands)."""
+import click
+
+from scape_amd.apa_core import infer_pa
+
+
+@click.group()
+def cli():
+    """SCAPE-APA `infer_pa` on AMD MI355X (HIP kernels behind the reference's CLI)."""
+
+
+def display_paper_info():
+    print()
+    print("scape infer_pa (MI355X/HIP build). Method: SCAPE-APA, Cheng, Le, Zhou, Cheng,")
+    print("bioRxiv 2024, https://doi.org/10.1101/2024.03.12.584547")
+    print()
+
+
+cli.add_command(infer_pa)

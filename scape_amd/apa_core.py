@@ -1,0 +1,176 @@
+"""``scape infer_pa`` on MI355X - host mirror of the reference's ``scape/apa_core.py`` surface.
+
+Same command line, same ``parameters.toml`` handling, same input chunk format and the
+same output stream of ``scape.apa_core.Parameters`` pickles as the reference
+(``/root/reference/src/scape/apa_core.py:40-147``, ``:236-258``, ``:984-1035``,
+``:1104-1137``); the per-UTR inference itself runs through ``scape_amd.engine`` on the
+GPU.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from pathlib import Path
+from timeit import default_timer as timer
+
+import click
+import numpy as np
+
+from . import safe_pickle
+from .engine import Engine
+from .host import prepare_utr
+
+try:  # Python >= 3.11
+    import tomllib as _toml
+except ModuleNotFoundError:  # pragma: no cover - 3.10 images
+    import tomli as _toml
+
+
+class Parameters:
+    """Result record, field-compatible with the reference class (apa_core.py:236-258);
+    pickles as ``scape.apa_core.Parameters`` so merge_pa & co. load it unchanged."""
+
+    def __init__(self, title='', alpha_arr=None, beta_arr=None, ws=None, L=None, cb_id_arr=None,
+                 readID_arr=None, K=None):
+        self.title = title
+        self.alpha_arr = alpha_arr
+        self.beta_arr = beta_arr
+        self.ws = ws
+        self.K = len(self.alpha_arr)
+        self.L = L
+        self.cb_id_arr = cb_id_arr
+        self.readID_arr = readID_arr
+
+    def __str__(self):
+        out = '-' * 10 + f'{self.title} K={self.K}' + '-' * 10 + '\n'
+        if hasattr(self, 'gene_info_str'):
+            out += f'gene info: {self.gene_info_str}\n'
+        out += f'K={self.K} L={self.L} Last component is uniform component.\n'
+        out += f'alpha_arr={self.alpha_arr}\n'
+        out += f'beta_arr={self.beta_arr}\n'
+        out += f'ws={np.around(self.ws, decimals=2)}\n'
+        if hasattr(self, 'bic'):
+            out += f'bic={np.around(self.bic, decimals=2)}\n'
+        out += '-' * 30 + '\n'
+        return out
+
+
+Parameters.__module__ = "scape.apa_core"
+Parameters.__qualname__ = "Parameters"
+
+
+def to_parameters(res):
+    """UtrResult -> Parameters with the reference's field set and dtypes."""
+    q, f = res.prep, res.fit
+    para = Parameters(title='Final Result',
+                      alpha_arr=np.rint(q.theta[f.a_idx]).astype('int'),
+                      beta_arr=q.betas[f.b_idx].astype(np.float64),
+                      ws=np.array(f.ws, dtype=np.float64), L=int(q.L),
+                      cb_id_arr=q.cb_id, readID_arr=q.read_id)
+    para.bic = np.float64(f.bic)
+    para.lb_arr = [np.float64(v) for v in f.lb]
+    para.label_arr = res.labels_bin.astype(np.int64)[q.idx]
+    para.gene_info_str = q.gene_info_str
+    return para
+
+
+def _dump_toml(d, fh):
+    """flat key = value writer (the reference uses tomli_w.dump, apa_core.py:98-99)."""
+    lines = []
+    for k, v in d.items():
+        if v is None:
+            continue
+        if isinstance(v, bool):
+            s = "true" if v else "false"
+        elif isinstance(v, (int, float)):
+            s = repr(v)
+        else:
+            s = '"' + str(v).replace("\\", "\\\\").replace('"', '\\"') + '"'
+        lines.append(f"{k} = {s}\n")
+    fh.write("".join(lines).encode())
+
+
+def read_input_chunk(path):
+    """Stream of (gene_info_str, DataFrame) tuples (input_processor.py:223-259).  Uses the
+    non-executing reader; SCAPE_TRUST_PICKLE=1 switches to pickle.load like the reference."""
+    if os.environ.get("SCAPE_TRUST_PICKLE") == "1":
+        with open(path, "rb") as fh:
+            while True:
+                try:
+                    yield pickle.load(fh)
+                except EOFError:
+                    return
+    else:
+        yield from safe_pickle.iter_pickles(path)
+
+
+def infer(pickle_input_file, pickle_output_file, **kwargs):
+    """Reference ``infer`` (apa_core.py:1104-1137): one Parameters per input tuple, same order."""
+    print(f"start inferring APA events from input pickle file = {pickle_input_file}. "
+          f"Output file = {pickle_output_file}")
+    start_t = timer()
+    preps = [prepare_utr(df, gene_info_str=gene, **kwargs) for gene, df in read_input_chunk(pickle_input_file)]
+    engine = Engine(device=kwargs.get("device"))
+    results = engine.run(preps, rng_mode=kwargs.get("rng_mode", "reference"), seed=int(kwargs.get("seed", 1)),
+                         re_run_mode=bool(kwargs.get("re_run_mode", True)))
+    res_lst = [to_parameters(r) for r in results]
+    for res in res_lst:
+        print(res)
+    print(f"Done {len(res_lst)} UTRs in {(timer() - start_t) / 60} min.")
+    with open(pickle_output_file, 'wb') as fh:
+        for res in res_lst:
+            print(f"save result of {res.gene_info_str}")
+            pickle.dump(res, fh)
+    return res_lst
+
+
+def _infer_pa(pkl_input_file: str, output_dir: str, **kwargs):
+    """Reference ``_infer_pa`` (apa_core.py:107-147)."""
+    if not os.path.exists(pkl_input_file):
+        raise Exception("Given input file does not exists")
+    os.makedirs(os.path.join(output_dir, "pkl_output"), exist_ok=True)
+    filename = os.path.basename(pkl_input_file)[:-10]          # strip ".input.pkl"
+    if ".tmp." in filename:
+        raise Exception("The input file " + filename + " is incomplete. Please re-run prepare_input() on " +
+                        filename.split(".")[0] + ".bam")
+    out_pkl_file = os.path.join(output_dir, "pkl_output", filename + ".res.pkl")
+    if os.path.exists(out_pkl_file):
+        os.remove(out_pkl_file)
+    if kwargs.get("fixed_run_mode", False):
+        raise NotImplementedError("fixed_run_mode / --pre_para_pkl_file is not implemented on the HIP path yet")
+    # watch_dog_flag (apa_core.py:140-145) is accepted and ignored: it only logs host CPU/memory
+    return infer(pkl_input_file, out_pkl_file, **kwargs)
+
+
+@click.command(name="infer_pa")
+@click.option('--pkl_input_file', type=str, help='input pickle file (result of prepare_input)', required=True)
+@click.option('--output_dir', type=str, help='output directory', required=True)
+@click.option('--toml_para_file', type=str, help='a TOML file specifies user-defined parameters', default=None,
+              required=False)
+@click.option('--pre_para_pkl_file', type=str,
+              help='a pickle file with pre-specified pA sites and utr length, result file of scape analysis',
+              default=None, required=False)
+def infer_pa(pkl_input_file: str, output_dir: str, toml_para_file: str = None, pre_para_pkl_file=None):
+    """Infer pA sites for every UTR of one prepare_input chunk (reference apa_core.py:40-104)."""
+    assert Path(output_dir).exists()
+    para_dict = {"n_max_apa": 5, "pre_para_pkl_file": pre_para_pkl_file}
+    if toml_para_file is None:
+        toml_para_file = Path(output_dir) / "parameters.toml"
+    if toml_para_file:
+        assert os.path.exists(toml_para_file)
+        with open(toml_para_file, "rb") as fh:
+            user_para_dict = _toml.load(fh)
+            para_dict.update(user_para_dict)
+        print(f"Parameter file {toml_para_file} loaded.")
+        for k, v in user_para_dict.items():
+            print(f"{k} = {v}")
+        print()
+    if pre_para_pkl_file:
+        assert os.path.exists(pre_para_pkl_file)
+        para_dict["fixed_run_mode"] = True
+        para_dict["pre_para_pkl_file"] = pre_para_pkl_file
+        with open(toml_para_file, 'wb') as fh:
+            _dump_toml(para_dict, fh)
+    if "output_dir" in para_dict:
+        del para_dict["output_dir"]
+    _infer_pa(pkl_input_file, output_dir, **para_dict)

@@ -1,0 +1,1308 @@
+// scape_hip.hip - gfx950 (MI355X) kernels + C ABI for SCAPE's infer_pa hot path.
+//
+// What is computed is specified by the reference's Python (citations: /root/reference/src/scape/):
+//   Phase A  point log-likelihoods        taichi_core.py:101-157, apa_core.py:954-957
+//   Phase B  marginal tensor over (a, b)  taichi_core.py:160-246
+//   EM       em_algo / mstep / elbo / bic apa_core.py:473-573, :702-779
+//   labels   get_label                    apa_core.py:873-881
+// How it is computed is MI355X-first: every array keeps the bin axis (n) fastest so that the
+// 64 lanes of a wavefront read/write consecutive f64; rows are padded to a 16-element pitch so
+// rows start 128-B aligned and can be read as double2; the EM kernel runs one workgroup per
+// (UTR, K, restart) job, keeps the responsibility column of the component being updated in LDS
+// and streams the tensor slab of the grid arg-max M-step with wavefront-shuffle reductions.
+// All arithmetic is f64 (the reference's finite -inf sentinel overflows f32).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scape_hip.h"
+
+#define SENT SCAPE_SENT
+#define PI_REF 3.141592653589793  // taichi_core.py:9
+#define PITCH 16                  // row pitch granule (f64 elements) -> 128-B aligned rows
+#define EM_THREADS 256
+#define EM_WAVES (EM_THREADS / 64)
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                        ":" + std::to_string(__LINE__) + ")");                               \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device-side descriptors
+// ------------------------------------------------------------------------------------------
+struct UtrDesc {
+    int64_t bin_off;    // first bin in x/l/r/pa/cnt
+    int64_t theta_off;  // first grid point in theta
+    int64_t at_off;     // offset (f64) of AT / V  [T][Np]
+    int64_t m_off;      // offset (f64) of M       [T][B][Np]
+    int64_t log_off;    // first entry in the log-domain bin list
+    int32_t N, Np, T, n_log;
+    double unif_ll, L, min_theta;
+};
+
+struct DevParams {
+    double mu_f, sigma_f, max_unif_ws;
+    int32_t B, S, nround, pad;
+    double betas[SCAPE_MAX_BETA];
+    double s_dis[SCAPE_MAX_S];
+    double pmf_s[SCAPE_MAX_S];
+};
+
+// ------------------------------------------------------------------------------------------
+// device functions: the reference's @ti.func set (taichi_core.py:24-97)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double d_logw(double w) { return (w <= 0.0) ? SENT : log(w); }
+__device__ __forceinline__ double d_logpdf_normal(double x, double mu, double sigma) {
+    double z = (x - mu) / sigma;
+    return -0.5 * (z * z) - log(sigma) - 0.5 * log(2 * PI_REF);
+}
+__device__ __forceinline__ double d_pdf_normal(double x, double mu, double sigma) {
+    double z = (x - mu) / sigma;
+    return exp(-0.5 * (z * z)) / sqrt(2 * PI_REF) / sigma;
+}
+
+// loglik_xlr_t_pa_kernel body (taichi_core.py:101-107)
+__device__ __forceinline__ double d_point_pa(double x, double l, double pa, double th, double sigma_f) {
+    double u = th - x;
+    double ll_l = (l <= u) ? -log(u) : SENT;
+    return ll_l + d_logpdf_normal(pa - th, 0.0, sigma_f);
+}
+// loglik_xlr_t_r_unknown_kernel body (taichi_core.py:141-157); returns v (linear), A through *a
+__device__ __forceinline__ double d_point_r_unknown(double x, double l, double th, const double *s,
+                                                    const double *pmf, int S, double mu_f,
+                                                    double sigma_f, double *a) {
+    double u = th - x;
+    double v = 0.0;
+    if (l <= u) {  // lik_l_xt == 0 otherwise, every term of the sum is then exactly 0
+        double lk = 1 / u;
+        for (int j = 0; j < S; ++j) v += 1 / s[j] * d_pdf_normal(x, th + s[j] - mu_f, sigma_f) * lk * pmf[j];
+    }
+    if (v < 1e-300) v = 0.0;
+    *a = (v <= 0.0) ? SENT : log(v);
+    return v;
+}
+// loglik_xlr_t_r_known_kernel body (taichi_core.py:111-132), two-pass logsumexp (:40-54)
+__device__ __forceinline__ double d_point_r_known(double x, double l, double r, double th,
+                                                  const double *s, const double *pmf, int S,
+                                                  double mu_f, double sigma_f) {
+    double u = th - x;
+    double ll_l = (l <= u) ? -log(u) : SENT;
+    double tmpn = 0.0, mx = 0.0;
+    for (int j = 0; j < S; ++j) {
+        double t;
+        if (s[j] < r) {
+            t = SENT;
+        } else {
+            tmpn += pmf[j];
+            double lrs = (r <= s[j]) ? -log(s[j]) : SENT;
+            t = lrs + d_logpdf_normal(x, th + s[j] - mu_f, sigma_f) + ll_l + log(pmf[j]);
+        }
+        if (j == 0 || t > mx) mx = t;
+    }
+    double sum = 0.0;
+    for (int j = 0; j < S; ++j) {
+        double t;
+        if (s[j] < r) {
+            t = SENT;
+        } else {
+            double lrs = (r <= s[j]) ? -log(s[j]) : SENT;
+            t = lrs + d_logpdf_normal(x, th + s[j] - mu_f, sigma_f) + ll_l + log(pmf[j]);
+        }
+        sum += exp(t - mx);
+    }
+    return log(sum) + mx - log(tmpn);
+}
+
+// np.sum over a short contiguous f64 run, in numpy's own order (sequential below 8 elements,
+// 8 interleaved accumulators above) so that row normalisations round like the reference's
+template <int CMAX>
+__device__ __forceinline__ double d_np_sum(const double (&a)[CMAX], int C) {
+    if (C < 8) {
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < (CMAX < 7 ? CMAX : 7); ++i)
+            if (i < C) r += a[i];
+        return r;
+    }
+    if constexpr (CMAX >= 8) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        const int lim = C - (C % 8);
+#pragma unroll
+        for (int i = 8; i + 8 <= CMAX; i += 8)
+            if (i < lim) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+            }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = 8; i < CMAX; ++i)
+            if (i >= lim && i < C) res += a[i];
+        return res;
+    }
+    return 0.0;
+}
+
+__device__ __forceinline__ double d_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+// ------------------------------------------------------------------------------------------
+// operator-level kernels (the taichi_core seam: one theta, one data subset)
+// ------------------------------------------------------------------------------------------
+__global__ void k_op_pa(const double *x, const double *l, const double *pa, int n, double theta,
+                        double sigma_f, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = d_point_pa(x[i], l[i], pa[i], theta, sigma_f);
+}
+__global__ void k_op_r_known(const double *x, const double *l, const double *r, int n, DevParams P,
+                             double theta, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = d_point_r_known(x[i], l[i], r[i], theta, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f);
+}
+__global__ void k_op_r_unknown(const double *x, const double *l, int n, DevParams P, double theta,
+                               double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double a;
+        d_point_r_unknown(x[i], l[i], theta, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a);
+        out[i] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Phase A: AT[t][n] = log p(bin n | theta_t) and V[t][n] = p(bin n | theta_t) (linear domain,
+// r-unknown bins only).  grid = (ceil(Np/256), T_max, n_utr); n is the lane axis.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_phase_a(const UtrDesc *__restrict__ descs, DevParams P,
+                                                 const double *__restrict__ x,
+                                                 const double *__restrict__ l,
+                                                 const double *__restrict__ r,
+                                                 const double *__restrict__ pa,
+                                                 const double *__restrict__ theta,
+                                                 double *__restrict__ AT, double *__restrict__ V) {
+    const UtrDesc d = descs[blockIdx.z];
+    const int t = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= d.T || n >= d.Np) return;
+    const size_t o = (size_t)d.at_off + (size_t)t * d.Np + n;
+    if (n >= d.N) {
+        AT[o] = 0.0;
+        V[o] = 0.0;
+        return;
+    }
+    const double th = theta[d.theta_off + t];
+    const double xn = x[d.bin_off + n], ln = l[d.bin_off + n];
+    const double rn = r[d.bin_off + n], pan = pa[d.bin_off + n];
+    double a, v = 0.0;
+    if (!isnan(pan)) {
+        a = d_point_pa(xn, ln, pan, th, P.sigma_f);
+    } else if (!isnan(rn)) {
+        a = d_point_r_known(xn, ln, rn, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f);
+    } else {
+        v = d_point_r_unknown(xn, ln, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a);
+    }
+    AT[o] = a;
+    V[o] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Phase B: M[i][j][n] = logsumexp_w( A[n,w] + logN(theta_w; theta_i, beta_j) - G_ij ) over the
+// +-3 beta window (taichi_core.py:218-234).  One workgroup per (UTR, i); the window weights of
+// all betas are built once in LDS.  r-unknown bins take the linear-domain form
+// log( sum_w V[w][n] * exp(g_w - G) ) - mathematically the same sum, no exp per term; bins
+// whose A was built in the log domain (pA-site / r-known) take the reference's two-pass form.
+// LDS layout (f64): g[B][Wmax] | p[B][Wmax] | G[B] | lo[B] hi[B] (int32 pairs)
+// ------------------------------------------------------------------------------------------
+template <int BMAX>
+__global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ descs, DevParams P,
+                                                 const double *__restrict__ r,
+                                                 const double *__restrict__ pa,
+                                                 const double *__restrict__ theta,
+                                                 const int32_t *__restrict__ loglist,
+                                                 const double *__restrict__ AT,
+                                                 const double *__restrict__ V,
+                                                 double *__restrict__ M, int Wmax, int all_log,
+                                                 int *__restrict__ err_flag) {
+    extern __shared__ double sm[];
+    const UtrDesc d = descs[blockIdx.y];
+    const int i = blockIdx.x;
+    if (i >= d.T) return;
+    const int B = P.B;
+    const int tid = threadIdx.x;
+    double *g = sm;                       // [B][Wmax]  logN(theta_w; theta_i, beta_j)
+    double *p = sm + (size_t)B * Wmax;    // [B][Wmax]  exp(g - G), 0 outside the window
+    double *G = p + (size_t)B * Wmax;     // [B]
+    int *lo = (int *)(G + B);             // [B]
+    int *hi = lo + B;                     // [B]
+    const double *th = theta + d.theta_off;
+    const double ti = th[i];
+
+    if (tid < B) {
+        const double beta = P.betas[tid];
+        int a = i, b = i;
+        const double lob = ti - 3 * beta, hib = ti + 3 * beta;
+        while (a > 0 && th[a - 1] >= lob) --a;          // searchsorted(left)
+        while (b + 1 < d.T && th[b + 1] <= hib) ++b;    // searchsorted(right) - 1
+        if (b - a + 1 > Wmax) {
+            atomicExch(err_flag, 1);
+            b = a + Wmax - 1;
+        }
+        lo[tid] = a;
+        hi[tid] = b;
+    }
+    __syncthreads();
+    for (int e = tid; e < B * Wmax; e += blockDim.x) {
+        const int j = e / Wmax, w = e - j * Wmax;
+        const int tw = lo[j] + w;
+        g[e] = (tw <= hi[j]) ? d_logpdf_normal(th[tw], ti, P.betas[j]) : 0.0;
+    }
+    __syncthreads();
+    if (tid < B) {  // call_logp_theta_sum_kernel (taichi_core.py:160-169), serial order
+        double psum = 0.0;
+        const int W = hi[tid] - lo[tid] + 1;
+        for (int w = 0; w < W; ++w) psum += exp(g[(size_t)tid * Wmax + w]);
+        G[tid] = log(psum);
+    }
+    __syncthreads();
+    int lo_all = lo[0], hi_all = hi[0];
+    for (int j = 1; j < B; ++j) {
+        lo_all = min(lo_all, lo[j]);
+        hi_all = max(hi_all, hi[j]);
+    }
+    const int Wall = hi_all - lo_all + 1;  // <= Wmax when windows nest (they do: symmetric in value)
+    // p re-indexed relative to lo_all so the linear path needs no per-beta window test
+    for (int e = tid; e < B * Wmax; e += blockDim.x) {
+        const int j = e / Wmax, w = e - j * Wmax;
+        const int tw = lo_all + w;
+        double val = 0.0;
+        if (w < Wall && tw >= lo[j] && tw <= hi[j]) val = exp(g[(size_t)j * Wmax + (tw - lo[j])] - G[j]);
+        p[e] = val;
+    }
+    __syncthreads();
+    if (Wall > Wmax) {
+        if (tid == 0) atomicExch(err_flag, 2);
+        return;
+    }
+
+    double *Mi = M + (size_t)d.m_off + (size_t)i * B * d.Np;
+    // ---- linear-domain path -----------------------------------------------------------------
+    if (!all_log) {
+        const double *Vu = V + (size_t)d.at_off;
+        for (int n = tid; n < d.Np; n += blockDim.x) {
+            if (n >= d.N) {
+                for (int j = 0; j < B; ++j) Mi[(size_t)j * d.Np + n] = 0.0;
+                continue;
+            }
+            if (!isnan(pa[d.bin_off + n]) || !isnan(r[d.bin_off + n])) continue;
+            if (B <= BMAX) {
+                double acc[BMAX];
+#pragma unroll
+                for (int j = 0; j < BMAX; ++j) acc[j] = 0.0;
+                for (int w = 0; w < Wall; ++w) {
+                    const double v = Vu[(size_t)(lo_all + w) * d.Np + n];
+#pragma unroll
+                    for (int j = 0; j < BMAX; ++j)
+                        if (j < B) acc[j] += v * p[(size_t)j * Wmax + w];
+                }
+#pragma unroll
+                for (int j = 0; j < BMAX; ++j)
+                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? log(acc[j]) : SENT;
+            } else {
+                for (int j = 0; j < B; ++j) {
+                    double acc = 0.0;
+                    for (int w = 0; w < Wall; ++w)
+                        acc += Vu[(size_t)(lo_all + w) * d.Np + n] * p[(size_t)j * Wmax + w];
+                    Mi[(size_t)j * d.Np + n] = (acc > 0.0) ? log(acc) : SENT;
+                }
+            }
+        }
+    } else {
+        for (int n = d.N + tid; n < d.Np; n += blockDim.x)
+            for (int j = 0; j < B; ++j) Mi[(size_t)j * d.Np + n] = 0.0;
+    }
+    // ---- log-domain path (cal_res_kernel, taichi_core.py:172-179) ------------------------------
+    const int n_log = all_log ? d.N : d.n_log;
+    const double *Au = AT + (size_t)d.at_off;
+    for (int item = tid; item < n_log * B; item += blockDim.x) {
+        const int j = item / n_log, q = item - j * n_log;
+        const int n = all_log ? q : loglist[d.log_off + q];
+        const int a = lo[j], W = hi[j] - lo[j] + 1;
+        const double Gj = G[j];
+        const double *gj = g + (size_t)j * Wmax;
+        double mx = Au[(size_t)a * d.Np + n] + gj[0] - Gj;
+        for (int w = 1; w < W; ++w) {
+            const double t = Au[(size_t)(a + w) * d.Np + n] + gj[w] - Gj;
+            if (t > mx) mx = t;
+        }
+        double sum = 0.0;
+        for (int w = 0; w < W; ++w) sum += exp(Au[(size_t)(a + w) * d.Np + n] + gj[w] - Gj - mx);
+        Mi[(size_t)j * d.Np + n] = log(sum) + mx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// EM: one workgroup per job (UTR, K, restart).  apa_core.py:714-779.
+// Column c of log_zmat is never stored: it is snap_lw[c] + M[snap_ia[c]][snap_ib[c]][:] where
+// the snapshot is what cal_z_k used the last time column c was refreshed (stale-column E-step,
+// apa_core.py:731).  Per round: one pass over the bins (responsibilities, weight sums, ELBO
+// terms, the Z[:,k]*cnt vector into LDS), then the grid arg-max over the (alpha, beta) window.
+// ------------------------------------------------------------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(EM_THREADS) void k_em(
+    const UtrDesc *__restrict__ descs, DevParams P, const double *__restrict__ cnt,
+    const double *__restrict__ M, int kmax, const int32_t *__restrict__ job_utr,
+    const int32_t *__restrict__ job_K, const int32_t *__restrict__ job_fixed,
+    const int32_t *__restrict__ a_in, const int32_t *__restrict__ b_in,
+    const double *__restrict__ ws_in, const int8_t *__restrict__ k_arr,
+    int32_t *__restrict__ a_out, int32_t *__restrict__ b_out, double *__restrict__ ws_out,
+    double *__restrict__ bic_out, int32_t *__restrict__ nlb_out, double *__restrict__ lb_out,
+    unsigned long long *__restrict__ counters) {
+    extern __shared__ double vk[];  // [Np] Z[:,k] * cnt of the component being updated
+    __shared__ double s_red[EM_WAVES][CMAX + 3];
+    __shared__ double s_tot[CMAX + 3];
+    __shared__ double s_ws[CMAX], s_snaplw[CMAX];
+    __shared__ int s_ia[CMAX], s_ib[CMAX], s_sia[CMAX], s_sib[CMAX];
+    __shared__ double s_best[EM_WAVES];
+    __shared__ int s_bestr[EM_WAVES];
+    __shared__ int s_flag;
+
+    const int job = blockIdx.x;
+    const UtrDesc d = descs[job_utr[job]];
+    const int K = job_K[job], C = K + 1;
+    const bool fixed = job_fixed[job] != 0;
+    const int B = P.B, nround = P.nround;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = d.N, Np = d.Np;
+    const double *Mu = M + (size_t)d.m_off;
+    const double *cu = cnt + d.bin_off;
+    const int8_t *ka = k_arr + (size_t)job * nround;
+    double *lb_arr = lb_out + (size_t)job * nround;
+
+    if (tid < C) {
+        s_ws[tid] = ws_in[(size_t)job * (kmax + 1) + tid];
+        s_snaplw[tid] = d_logw(s_ws[tid]);                                   // :722-724
+        if (tid < K) {
+            s_ia[tid] = s_sia[tid] = a_in[(size_t)job * kmax + tid];
+            s_ib[tid] = s_sib[tid] = b_in[(size_t)job * kmax + tid];
+        }
+    }
+    __syncthreads();
+
+    double lb = SENT, ell_last = 0.0;
+    int n_lb = 0;
+    unsigned long long slab_rows = 0;
+
+    for (int it = 0; it < nround; ++it) {
+        const int k = ka[it];
+        if (tid == 0) {  // cal_z_k(para, k_arr[i]) (:731): refresh the snapshot of column k
+            s_snaplw[k] = d_logw(s_ws[k]);
+            if (k < K) {
+                s_sia[k] = s_ia[k];
+                s_sib[k] = s_ib[k];
+            }
+        }
+        __syncthreads();
+
+        size_t roff[CMAX];
+        double slw[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            roff[c] = (c < K) ? ((size_t)s_sia[c] * B + s_sib[c]) * Np : 0;
+            slw[c] = (c < C) ? s_snaplw[c] : 0.0;
+        }
+
+        // ---- E pass (norm_z :490-495, mstep head :525-529, maximize_ws numerators :499,
+        //      exp_log_lik :570-573, entropy :560) ; second pass only if Z[:,k] += 1e-8 fires
+        double tot[CMAX + 3];
+        bool mod = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            double wsum[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) wsum[c] = 0.0;
+            double sumk = 0.0, ell = 0.0, ent = 0.0;
+            for (int n = tid; n < Np; n += EM_THREADS) {
+                double vkn = 0.0;
+                if (n < N) {
+                    const double cn = cu[n];
+                    double lz[CMAX], z[CMAX];
+                    double mx = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < C) {
+                            lz[c] = (c < K) ? slw[c] + Mu[roff[c] + n] : slw[c] + d.unif_ll;
+                            mx = (c == 0 || lz[c] > mx) ? lz[c] : mx;
+                        } else {
+                            lz[c] = 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) z[c] = (c < C) ? exp((lz[c] - mx) * cn) : 0.0;
+                    const double s = d_np_sum<CMAX>(z, C);
+                    double zk = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        z[c] = z[c] / s;
+                        if (c == k) {
+                            sumk += z[c];
+                            if (mod) z[c] += 1e-8;
+                            zk = z[c];
+                        }
+                    }
+                    const double s2 = d_np_sum<CMAX>(z, C);
+                    double e[CMAX];
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < C) {
+                            wsum[c] += cn * z[c];
+                            if (z[c] != 0.0) ell += (z[c] * cn) * lz[c];
+                            const double pk = z[c] / s2;
+                            e[c] = (pk > 0.0) ? -pk * log(pk) : 0.0;
+                        } else {
+                            e[c] = 0.0;
+                        }
+                    }
+                    ent += cn * d_np_sum<CMAX>(e, C);
+                    vkn = zk * cn;
+                }
+                vk[n] = vkn;
+            }
+            // block reduction (fixed order: lane tree, then waves 0..3)
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                const double v = d_wave_sum(wsum[c]);
+                if (lane == 0) s_red[wave][c] = v;
+            }
+            {
+                double v = d_wave_sum(sumk);
+                if (lane == 0) s_red[wave][CMAX] = v;
+                v = d_wave_sum(ell);
+                if (lane == 0) s_red[wave][CMAX + 1] = v;
+                v = d_wave_sum(ent);
+                if (lane == 0) s_red[wave][CMAX + 2] = v;
+            }
+            __syncthreads();
+            if (tid < CMAX + 3) {
+                double v = 0.0;
+                for (int w = 0; w < EM_WAVES; ++w) v += s_red[w][tid];
+                s_tot[tid] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CMAX + 3; ++c) tot[c] = s_tot[c];
+            if (pass == 0 && tot[CMAX] < 1e-8) {
+                mod = true;  // redo the pass with Z[:,k] += 1e-8 (apa_core.py:528-529)
+                __syncthreads();
+                continue;
+            }
+            break;
+        }
+
+        // ---- maximize_ws (:498-505), all threads redundantly (uniform) ----------------------
+        double wn[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) wn[c] = (c < C) ? tot[c] : 0.0;
+        {
+            const double s = d_np_sum<CMAX>(wn, C);
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) wn[c] = wn[c] / s;
+            double wK = 0.0;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c == K) wK = wn[c];
+            if (wK > P.max_unif_ws) {
+                const double sk = d_np_sum<CMAX>(wn, K);
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    if (c < K) wn[c] = (1 - P.max_unif_ws) * wn[c] / sk;
+                    if (c == K) wn[c] = P.max_unif_ws;
+                }
+            }
+        }
+        double wk_new = 0.0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c == k) wk_new = wn[c];
+        if (tid < CMAX) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c == tid && c < C) s_ws[c] = wn[c];
+        }
+
+        // ---- max_alpha_beta (:507-523): first arg-max over the inclusive theta window --------
+        if (!fixed && k < K) {
+            const int lo = (k == 0) ? 0 : s_ia[k - 1];
+            const int hi = (k == K - 1) ? d.T - 1 : s_ia[k + 1];
+            const double lw = d_logw(wk_new);
+            const int r0 = lo * B, r1 = (hi + 1) * B;
+            double best = -INFINITY;
+            int best_r = r0;
+            const int nq = Np >> 1;
+            const double2 *vk2 = reinterpret_cast<const double2 *>(vk);
+            for (int rr = r0 + wave; rr < r1; rr += EM_WAVES) {
+                const double2 *row = reinterpret_cast<const double2 *>(Mu + (size_t)rr * Np);
+                double acc0 = 0.0, acc1 = 0.0;
+                for (int q = lane; q < nq; q += 64) {
+                    const double2 m = row[q];
+                    const double2 v = vk2[q];
+                    acc0 += (lw + m.x) * v.x;
+                    acc1 += (lw + m.y) * v.y;
+                }
+                const double sc = d_wave_sum(acc0 + acc1);
+                if (lane == 0 && sc > best) {
+                    best = sc;
+                    best_r = rr;
+                }
+            }
+            if (lane == 0) {
+                s_best[wave] = best;
+                s_bestr[wave] = best_r;
+            }
+            slab_rows += (unsigned long long)(r1 - r0);
+            __syncthreads();
+            if (tid == 0) {
+                double bb = s_best[0];
+                int br = s_bestr[0];
+                for (int w = 1; w < EM_WAVES; ++w)
+                    if (s_best[w] > bb || (s_best[w] == bb && s_bestr[w] < br)) {
+                        bb = s_best[w];
+                        br = s_bestr[w];
+                    }
+                if (lo <= hi) {
+                    s_ia[k] = br / B;
+                    s_ib[k] = br - (br / B) * B;
+                }
+            }
+        }
+
+        // ---- elbo (:559-561) and the stopping rule (:743-746), uniform across threads --------
+        const double lb_new = tot[CMAX + 1] + tot[CMAX + 2];
+        ell_last = tot[CMAX + 1];
+        if (tid == 0) lb_arr[n_lb] = lb_new;
+        ++n_lb;
+        const bool stop = fabs(lb_new - lb) < fabs(1e-6 * lb);
+        lb = lb_new;
+        __syncthreads();
+        if (stop) break;
+    }
+
+    // ---- cal_bic (:702-706), sort by alpha (:768-772), outputs -------------------------------
+    if (tid == 0) {
+        bic_out[job] = -2 * ell_last + (3 * K + 1) * log((double)N);
+        nlb_out[job] = n_lb;
+        int idx[CMAX];
+        for (int i = 0; i < K; ++i) idx[i] = i;
+        for (int i = 1; i < K; ++i) {  // stable insertion sort == numpy argsort for K <= 16
+            const int v = idx[i];
+            int j = i - 1;
+            while (j >= 0 && s_ia[idx[j]] > s_ia[v]) {
+                idx[j + 1] = idx[j];
+                --j;
+            }
+            idx[j + 1] = v;
+        }
+        for (int i = 0; i < K; ++i) {
+            a_out[(size_t)job * kmax + i] = s_ia[idx[i]];
+            b_out[(size_t)job * kmax + i] = s_ib[idx[i]];
+            ws_out[(size_t)job * (kmax + 1) + i] = s_ws[idx[i]];
+        }
+        ws_out[(size_t)job * (kmax + 1) + K] = s_ws[K];
+        for (int i = K; i < kmax; ++i) {
+            a_out[(size_t)job * kmax + i] = -1;
+            b_out[(size_t)job * kmax + i] = -1;
+            ws_out[(size_t)job * (kmax + 1) + i + 1] = 0.0;
+        }
+        atomicAdd(&counters[0], (unsigned long long)n_lb);
+        atomicAdd(&counters[1], slab_rows * (unsigned long long)N);
+        atomicAdd(&counters[2], (unsigned long long)n_lb * (unsigned long long)N * (unsigned long long)C);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// labels: get_label (apa_core.py:873-881), one workgroup per selected model
+// ------------------------------------------------------------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void k_labels(const UtrDesc *__restrict__ descs, DevParams P,
+                                                const double *__restrict__ cnt,
+                                                const double *__restrict__ M, int kmax,
+                                                const int32_t *__restrict__ sel_utr,
+                                                const int32_t *__restrict__ sel_K,
+                                                const int32_t *__restrict__ a_in,
+                                                const int32_t *__restrict__ b_in,
+                                                const double *__restrict__ ws_in,
+                                                int32_t *__restrict__ labels) {
+    const int sel = blockIdx.x;
+    const UtrDesc d = descs[sel_utr[sel]];
+    const int K = sel_K[sel], C = K + 1, B = P.B;
+    const double *Mu = M + (size_t)d.m_off;
+    size_t roff[CMAX];
+    double slw[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        roff[c] = (c < K) ? ((size_t)a_in[(size_t)sel * kmax + c] * B + b_in[(size_t)sel * kmax + c]) * d.Np : 0;
+        slw[c] = (c < C) ? d_logw(ws_in[(size_t)sel * (kmax + 1) + c]) : 0.0;
+    }
+    for (int n = threadIdx.x; n < d.N; n += blockDim.x) {
+        const double cn = cnt[d.bin_off + n];
+        double lz[CMAX], z[CMAX], mx = 0.0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C) {
+                lz[c] = (c < K) ? slw[c] + Mu[roff[c] + n] : slw[c] + d.unif_ll;
+                mx = (c == 0 || lz[c] > mx) ? lz[c] : mx;
+            } else {
+                lz[c] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) z[c] = (c < C) ? exp((lz[c] - mx) * cn) : 0.0;
+        const double s = d_np_sum<CMAX>(z, C);
+        int best = 0;
+        double bz = 0.0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            const double zc = z[c] / s;
+            if (c < C && (c == 0 || zc > bz)) {
+                bz = zc;
+                best = c;
+            }
+        }
+        labels[d.bin_off + n] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap && p) return 0;
+        if (p) {
+            (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+        }
+        if (bytes == 0) bytes = 16;
+        HIPCHK(hipMalloc(&p, bytes));
+        cap = bytes;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct scape_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char name[256] = {0};
+    DevParams prm;
+    bool loaded = false, built = false;
+    int n_utr = 0, T_max = 0, Np_max = 0, W_max = 1;
+    int64_t n_bins = 0;
+    std::vector<UtrDesc> h_desc;
+    size_t at_total = 0, m_total = 0;
+    DevBuf d_x, d_l, d_r, d_pa, d_cnt, d_theta, d_desc, d_loglist, d_AT, d_V, d_M, d_err, d_counters;
+    DevBuf j_utr, j_K, j_fixed, j_a, j_b, j_ws, j_karr, j_ao, j_bo, j_wso, j_bic, j_nlb, j_lb;
+    DevBuf l_utr, l_K, l_a, l_b, l_ws, l_labels;
+    std::vector<EventPair> ev[4];
+    double ms_acc[4] = {0, 0, 0, 0};
+    int n_acc[4] = {0, 0, 0, 0};
+    unsigned long long h_counters[3] = {0, 0, 0};
+};
+
+static int ev_begin(scape_hip_ctx *c, int which) {
+    EventPair e;
+    HIPCHK(hipEventCreate(&e.a));
+    HIPCHK(hipEventCreate(&e.b));
+    HIPCHK(hipEventRecord(e.a, c->stream));
+    c->ev[which].push_back(e);
+    return 0;
+}
+static int ev_end(scape_hip_ctx *c, int which) {
+    HIPCHK(hipEventRecord(c->ev[which].back().b, c->stream));
+    return 0;
+}
+static int ev_collect(scape_hip_ctx *c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int w = 0; w < 4; ++w) {
+        for (auto &e : c->ev[w]) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            c->ms_acc[w] += ms;
+            c->n_acc[w] += 1;
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        c->ev[w].clear();
+    }
+    return 0;
+}
+
+static int round_up(int v, int g) { return (v + g - 1) / g * g; }
+
+static int set_device(scape_hip_ctx *c) {
+    HIPCHK(hipSetDevice(c->device));
+    return 0;
+}
+
+static void fill_params(DevParams &d, double mu_f, double sigma_f, double max_unif_ws, int B,
+                        const double *betas, int S, const double *s, const double *pmf, int nround) {
+    memset(&d, 0, sizeof(d));
+    d.mu_f = mu_f;
+    d.sigma_f = sigma_f;
+    d.max_unif_ws = max_unif_ws;
+    d.B = B;
+    d.S = S;
+    d.nround = nround;
+    for (int i = 0; i < B; ++i) d.betas[i] = betas[i];
+    for (int i = 0; i < S; ++i) {
+        d.s_dis[i] = s[i];
+        d.pmf_s[i] = pmf[i];
+    }
+}
+
+// widest +-3*beta window (in grid points) over all grid points of one theta grid
+static int max_window(const double *th, int T, double beta) {
+    int best = 1, a = 0, b = 0;
+    for (int i = 0; i < T; ++i) {
+        const double lo = th[i] - 3 * beta, hi = th[i] + 3 * beta;
+        while (a < i && th[a] < lo) ++a;
+        if (b < i) b = i;
+        while (b + 1 < T && th[b + 1] <= hi) ++b;
+        best = std::max(best, b - a + 1);
+    }
+    return best;
+}
+
+static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int T_max, int Wmax,
+                          const UtrDesc *d_desc, const double *d_r, const double *d_pa,
+                          const double *d_theta, const int32_t *d_loglist, const double *d_AT,
+                          const double *d_V, double *d_M, int all_log) {
+    if (c->d_err.ensure(sizeof(int))) return 1;
+    HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
+    const size_t lds = ((size_t)2 * prm.B * Wmax + prm.B) * sizeof(double) + (size_t)2 * prm.B * sizeof(int);
+    if (lds > 150 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
+    dim3 grid(T_max, n_utr);
+    if (prm.B <= 16)
+        hipLaunchKernelGGL(k_phase_b<16>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>());
+    else
+        hipLaunchKernelGGL(k_phase_b<1>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>());
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int check_err_flag(scape_hip_ctx *c, const char *what) {
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, c->d_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (flag) return fail(std::string(what) + ": device-side consistency check failed (flag " + std::to_string(flag) + ")");
+    return 0;
+}
+
+extern "C" {
+
+int scape_hip_abi_version(void) { return SCAPE_HIP_ABI_VERSION; }
+const char *scape_hip_last_error(void) { return g_err.c_str(); }
+
+int scape_hip_device_count(int *count) {
+    if (!count) return fail("count is NULL");
+    HIPCHK(hipGetDeviceCount(count));
+    return 0;
+}
+
+int scape_hip_create(int device, scape_hip_ctx **out) {
+    if (!out) return fail("out is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("no such HIP device: " + std::to_string(device));
+    HIPCHK(hipSetDevice(device));
+    scape_hip_ctx *c = new scape_hip_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    HIPCHK(hipStreamCreate(&c->stream));
+    if (c->d_counters.ensure(3 * sizeof(unsigned long long))) return 1;
+    *out = c;
+    return 0;
+}
+
+int scape_hip_device_name(scape_hip_ctx *c, char *buf, int buflen) {
+    if (!c || !buf || buflen <= 0) return fail("bad argument");
+    snprintf(buf, buflen, "%s", c->name);
+    return 0;
+}
+
+int scape_hip_batch_free(scape_hip_ctx *c) {
+    if (!c) return fail("ctx is NULL");
+    if (set_device(c)) return 1;
+    DevBuf *all[] = {&c->d_x, &c->d_l, &c->d_r, &c->d_pa, &c->d_cnt, &c->d_theta, &c->d_desc, &c->d_loglist,
+                     &c->d_AT, &c->d_V, &c->d_M, &c->j_utr, &c->j_K, &c->j_fixed, &c->j_a, &c->j_b, &c->j_ws,
+                     &c->j_karr, &c->j_ao, &c->j_bo, &c->j_wso, &c->j_bic, &c->j_nlb, &c->j_lb, &c->l_utr,
+                     &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels};
+    for (DevBuf *b : all) b->release();
+    c->loaded = c->built = false;
+    c->n_utr = 0;
+    return 0;
+}
+
+int scape_hip_destroy(scape_hip_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    scape_hip_batch_free(c);
+    c->d_err.release();
+    c->d_counters.release();
+    for (int w = 0; w < 4; ++w)
+        for (auto &e : c->ev[w]) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+// ---- operator level ------------------------------------------------------------------------
+static int op_common(scape_hip_ctx *c, int n, const double *const *in, int n_in, double **dev, double **dout) {
+    if (!c) return fail("ctx is NULL");
+    if (n < 0) return fail("negative length");
+    if (set_device(c)) return 1;
+    for (int i = 0; i < n_in; ++i) {
+        if (!in[i] && n > 0) return fail("NULL input array");
+        HIPCHK(hipMalloc((void **)&dev[i], std::max<size_t>(16, (size_t)n * sizeof(double))));
+        if (n) HIPCHK(hipMemcpyAsync(dev[i], in[i], (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipMalloc((void **)dout, std::max<size_t>(16, (size_t)n * sizeof(double))));
+    return 0;
+}
+static int op_finish(scape_hip_ctx *c, int n, double **dev, int n_in, double *dout, double *out) {
+    int rc = 0;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(std::string("kernel launch: ") + hipGetErrorString(e));
+    if (!rc && n) {
+        e = hipMemcpyAsync(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(std::string("copy back: ") + hipGetErrorString(e));
+    }
+    e = hipStreamSynchronize(c->stream);
+    if (!rc && e != hipSuccess) rc = fail(std::string("sync: ") + hipGetErrorString(e));
+    for (int i = 0; i < n_in; ++i) (void)hipFree(dev[i]);
+    (void)hipFree(dout);
+    return rc;
+}
+
+int scape_hip_loglik_xlr_t_pa(scape_hip_ctx *c, const double *x, const double *l, const double *pa,
+                              int32_t n, double theta, double sigma_f, double *out) {
+    const double *in[3] = {x, l, pa};
+    double *dev[3] = {nullptr, nullptr, nullptr}, *dout = nullptr;
+    if (op_common(c, n, in, 3, dev, &dout)) return 1;
+    if (n) hipLaunchKernelGGL(k_op_pa, dim3((n + 255) / 256), dim3(256), 0, c->stream, dev[0], dev[1], dev[2], n, theta, sigma_f, dout);
+    return op_finish(c, n, dev, 3, dout, out);
+}
+
+int scape_hip_loglik_xlr_t_r_known(scape_hip_ctx *c, const double *x, const double *l, const double *r,
+                                   int32_t n, const double *s_dis, const double *pmf_s, int32_t n_s,
+                                   double theta, double mu_f, double sigma_f, double *out) {
+    if (n_s < 1 || n_s > SCAPE_MAX_S) return fail("n_s out of range");
+    DevParams P;
+    fill_params(P, mu_f, sigma_f, 0, 0, nullptr, n_s, s_dis, pmf_s, 0);
+    const double *in[3] = {x, l, r};
+    double *dev[3] = {nullptr, nullptr, nullptr}, *dout = nullptr;
+    if (op_common(c, n, in, 3, dev, &dout)) return 1;
+    if (n) hipLaunchKernelGGL(k_op_r_known, dim3((n + 255) / 256), dim3(256), 0, c->stream, dev[0], dev[1], dev[2], n, P, theta, dout);
+    return op_finish(c, n, dev, 3, dout, out);
+}
+
+int scape_hip_loglik_xlr_t_r_unknown(scape_hip_ctx *c, const double *x, const double *l, const double *r,
+                                     int32_t n, const double *s_dis, const double *pmf_s, int32_t n_s,
+                                     double theta, double mu_f, double sigma_f, double *out) {
+    (void)r;
+    if (n_s < 1 || n_s > SCAPE_MAX_S) return fail("n_s out of range");
+    DevParams P;
+    fill_params(P, mu_f, sigma_f, 0, 0, nullptr, n_s, s_dis, pmf_s, 0);
+    const double *in[2] = {x, l};
+    double *dev[2] = {nullptr, nullptr}, *dout = nullptr;
+    if (op_common(c, n, in, 2, dev, &dout)) return 1;
+    if (n) hipLaunchKernelGGL(k_op_r_unknown, dim3((n + 255) / 256), dim3(256), 0, c->stream, dev[0], dev[1], n, P, theta, dout);
+    return op_finish(c, n, dev, 2, dout, out);
+}
+
+int scape_hip_get_loglik_marginal_tensor(scape_hip_ctx *c, const double *all_theta, int32_t T,
+                                         const double *betas, int32_t B, const double *A, int32_t N,
+                                         double *out) {
+    if (!c) return fail("ctx is NULL");
+    if (T < 1 || N < 1) return fail("empty theta grid or no fragments");
+    if (B < 1 || B > SCAPE_MAX_BETA) return fail("n_beta out of range");
+    if (!all_theta || !betas || !A || !out) return fail("NULL argument");
+    if (set_device(c)) return 1;
+    for (int i = 1; i < T; ++i)
+        if (!(all_theta[i] >= all_theta[i - 1])) return fail("all_theta must be ascending");
+    DevParams P;
+    fill_params(P, 0, 1, 0, B, betas, 0, nullptr, nullptr, 0);
+    const int Np = round_up(N, PITCH);
+    double bmax = betas[0];
+    for (int j = 1; j < B; ++j) bmax = std::max(bmax, betas[j]);
+    const int Wmax = max_window(all_theta, T, bmax);
+    std::vector<double> at((size_t)T * Np, 0.0);
+    for (int n = 0; n < N; ++n)
+        for (int t = 0; t < T; ++t) at[(size_t)t * Np + n] = A[(size_t)n * T + t];
+    UtrDesc d;
+    memset(&d, 0, sizeof(d));
+    d.N = N;
+    d.Np = Np;
+    d.T = T;
+    DevBuf dAT, dM, dth, ddesc;
+    int rc = 0;
+    auto cleanup = [&]() {
+        dAT.release();
+        dM.release();
+        dth.release();
+        ddesc.release();
+    };
+    if (dAT.ensure(at.size() * sizeof(double)) || dM.ensure((size_t)T * B * Np * sizeof(double)) ||
+        dth.ensure((size_t)T * sizeof(double)) || ddesc.ensure(sizeof(UtrDesc))) {
+        cleanup();
+        return 1;
+    }
+    hipError_t e;
+    e = hipMemcpyAsync(dAT.p, at.data(), at.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dth.p, all_theta, (size_t)T * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ddesc.p, &d, sizeof(d), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(std::string("upload: ") + hipGetErrorString(e));
+    }
+    rc = launch_phase_b(c, P, 1, T, Wmax, ddesc.as<UtrDesc>(), nullptr, nullptr, dth.as<double>(), nullptr,
+                        dAT.as<double>(), nullptr, dM.as<double>(), 1);
+    if (!rc) rc = check_err_flag(c, "get_loglik_marginal_tensor");
+    if (!rc) {
+        e = hipMemcpy2DAsync(out, (size_t)N * sizeof(double), dM.p, (size_t)Np * sizeof(double),
+                             (size_t)N * sizeof(double), (size_t)T * B, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(std::string("copy back: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+// ---- batched level ---------------------------------------------------------------------------
+int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_utr, const int64_t *bin_off,
+                         const double *x, const double *l, const double *r, const double *pa,
+                         const double *cnt, const int64_t *theta_off, const double *all_theta,
+                         const double *utr_L, const double *min_theta, const double *unif_ll) {
+    if (!c || !p) return fail("NULL ctx/params");
+    if (n_utr < 1 || n_utr > 65535) return fail("n_utr must be in [1, 65535] per batch");
+    if (p->n_beta < 1 || p->n_beta > SCAPE_MAX_BETA) return fail("n_beta out of range");
+    if (p->n_s < 1 || p->n_s > SCAPE_MAX_S) return fail("n_s out of range");
+    if (p->nround < 1 || p->nround > 127) return fail("nround out of range");
+    if (!bin_off || !x || !l || !r || !pa || !cnt || !theta_off || !all_theta || !utr_L || !min_theta || !unif_ll)
+        return fail("NULL array argument");
+    if (set_device(c)) return 1;
+    c->loaded = c->built = false;
+    fill_params(c->prm, p->mu_f, p->sigma_f, p->max_unif_ws, p->n_beta, p->betas, p->n_s, p->s_dis, p->pmf_s, p->nround);
+    double bmax = p->betas[0];
+    for (int j = 1; j < p->n_beta; ++j) bmax = std::max(bmax, p->betas[j]);
+
+    c->h_desc.assign(n_utr, UtrDesc());
+    std::vector<int32_t> loglist;
+    size_t at_total = 0, m_total = 0;
+    int T_max = 0, Np_max = 0, W_max = 1;
+    for (int u = 0; u < n_utr; ++u) {
+        UtrDesc &d = c->h_desc[u];
+        const int64_t N = bin_off[u + 1] - bin_off[u], T = theta_off[u + 1] - theta_off[u];
+        if (N < 1 || T < 1 || N > (1 << 26) || T > 65535) return fail("UTR " + std::to_string(u) + ": bad n_frag / n_theta");
+        const double *th = all_theta + theta_off[u];
+        for (int64_t i = 1; i < T; ++i)
+            if (!(th[i] >= th[i - 1])) return fail("UTR " + std::to_string(u) + ": all_theta must be ascending");
+        d.bin_off = bin_off[u];
+        d.theta_off = theta_off[u];
+        d.N = (int)N;
+        d.Np = round_up((int)N, PITCH);
+        d.T = (int)T;
+        d.at_off = (int64_t)at_total;
+        d.m_off = (int64_t)m_total;
+        d.log_off = (int64_t)loglist.size();
+        for (int64_t n = 0; n < N; ++n)
+            if (!std::isnan(pa[bin_off[u] + n]) || !std::isnan(r[bin_off[u] + n])) loglist.push_back((int32_t)n);
+        d.n_log = (int)(loglist.size() - (size_t)d.log_off);
+        d.unif_ll = unif_ll[u];
+        d.L = utr_L[u];
+        d.min_theta = min_theta[u];
+        at_total += (size_t)T * d.Np;
+        m_total += (size_t)T * p->n_beta * d.Np;
+        T_max = std::max(T_max, d.T);
+        Np_max = std::max(Np_max, d.Np);
+        W_max = std::max(W_max, max_window(th, d.T, bmax));
+    }
+    if ((size_t)Np_max * sizeof(double) > 150 * 1024) return fail("n_frag too large for the LDS-resident EM kernel");
+    const int64_t nb = bin_off[n_utr], nt = theta_off[n_utr];
+    c->n_utr = n_utr;
+    c->n_bins = nb;
+    c->T_max = T_max;
+    c->Np_max = Np_max;
+    c->W_max = W_max;
+    c->at_total = at_total;
+    c->m_total = m_total;
+    if (c->d_x.ensure(nb * 8) || c->d_l.ensure(nb * 8) || c->d_r.ensure(nb * 8) || c->d_pa.ensure(nb * 8) ||
+        c->d_cnt.ensure(nb * 8) || c->d_theta.ensure(nt * 8) || c->d_desc.ensure(n_utr * sizeof(UtrDesc)) ||
+        c->d_loglist.ensure(loglist.size() * 4) || c->d_AT.ensure(at_total * 8) || c->d_V.ensure(at_total * 8) ||
+        c->d_M.ensure(m_total * 8))
+        return 1;
+    HIPCHK(hipMemcpyAsync(c->d_x.p, x, nb * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_l.p, l, nb * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_r.p, r, nb * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_pa.p, pa, nb * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_cnt.p, cnt, nb * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_theta.p, all_theta, nt * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_desc.p, c->h_desc.data(), n_utr * sizeof(UtrDesc), hipMemcpyHostToDevice, c->stream));
+    if (!loglist.empty())
+        HIPCHK(hipMemcpyAsync(c->d_loglist.p, loglist.data(), loglist.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->loaded = true;
+    return 0;
+}
+
+int scape_hip_batch_bytes(scape_hip_ctx *c, int64_t *bytes_batch, int64_t *bytes_free, int64_t *bytes_total) {
+    if (!c) return fail("ctx is NULL");
+    if (set_device(c)) return 1;
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (bytes_batch) *bytes_batch = c->loaded ? (int64_t)((2 * c->at_total + c->m_total) * 8 + c->n_bins * 40) : 0;
+    if (bytes_free) *bytes_free = (int64_t)f;
+    if (bytes_total) *bytes_total = (int64_t)t;
+    return 0;
+}
+
+int scape_hip_batch_build(scape_hip_ctx *c) {
+    if (!c) return fail("ctx is NULL");
+    if (!c->loaded) return fail("no batch loaded");
+    if (set_device(c)) return 1;
+    dim3 grid((c->Np_max + 255) / 256, c->T_max, c->n_utr);
+    if (ev_begin(c, 0)) return 1;
+    hipLaunchKernelGGL(k_phase_a, grid, dim3(256), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm, c->d_x.as<double>(),
+                       c->d_l.as<double>(), c->d_r.as<double>(), c->d_pa.as<double>(), c->d_theta.as<double>(),
+                       c->d_AT.as<double>(), c->d_V.as<double>());
+    HIPCHK(hipGetLastError());
+    if (ev_end(c, 0)) return 1;
+    if (ev_begin(c, 1)) return 1;
+    if (launch_phase_b(c, c->prm, c->n_utr, c->T_max, c->W_max, c->d_desc.as<UtrDesc>(), c->d_r.as<double>(),
+                       c->d_pa.as<double>(), c->d_theta.as<double>(), c->d_loglist.as<int32_t>(),
+                       c->d_AT.as<double>(), c->d_V.as<double>(), c->d_M.as<double>(), 0))
+        return 1;
+    if (ev_end(c, 1)) return 1;
+    if (check_err_flag(c, "batch_build")) return 1;
+    c->built = true;
+    return 0;
+}
+
+int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int32_t *job_utr,
+                       const int32_t *job_K, const int32_t *job_fixed, const int32_t *alpha_idx,
+                       const int32_t *beta_idx, const double *ws, const int8_t *k_arr,
+                       int32_t *alpha_idx_out, int32_t *beta_idx_out, double *ws_out, double *bic_out,
+                       int32_t *n_lb_out, double *lb_out) {
+    if (!c) return fail("ctx is NULL");
+    if (!c->built) return fail("batch_build has not run");
+    if (n_jobs < 1) return fail("n_jobs < 1");
+    if (kmax < 1 || kmax > SCAPE_MAX_K) return fail("kmax out of range");
+    if (!job_utr || !job_K || !job_fixed || !alpha_idx || !beta_idx || !ws || !k_arr || !alpha_idx_out ||
+        !beta_idx_out || !ws_out || !bic_out || !n_lb_out || !lb_out)
+        return fail("NULL array argument");
+    if (set_device(c)) return 1;
+    const int nround = c->prm.nround, B = c->prm.B;
+    // host-side validation: every index a kernel dereferences is checked here
+    for (int j = 0; j < n_jobs; ++j) {
+        const int u = job_utr[j], K = job_K[j];
+        if (u < 0 || u >= c->n_utr) return fail("job " + std::to_string(j) + ": bad UTR index");
+        if (K < 0 || K > kmax) return fail("job " + std::to_string(j) + ": K out of range");
+        const int T = c->h_desc[u].T;
+        for (int k = 0; k < K; ++k) {
+            const int a = alpha_idx[(size_t)j * kmax + k], b = beta_idx[(size_t)j * kmax + k];
+            if (a < 0 || a >= T || b < 0 || b >= B) return fail("job " + std::to_string(j) + ": alpha/beta index out of range");
+            if (k > 0 && a < alpha_idx[(size_t)j * kmax + k - 1]) return fail("job " + std::to_string(j) + ": alpha indices must be non-decreasing");
+        }
+        for (int t = 0; t < nround; ++t) {
+            const int k = k_arr[(size_t)j * nround + t];
+            if (k < 0 || k > K || (K > 0 && k >= K)) return fail("job " + std::to_string(j) + ": k_arr entry out of range");
+        }
+    }
+    const size_t nj = n_jobs;
+    if (c->j_utr.ensure(nj * 4) || c->j_K.ensure(nj * 4) || c->j_fixed.ensure(nj * 4) || c->j_a.ensure(nj * kmax * 4) ||
+        c->j_b.ensure(nj * kmax * 4) || c->j_ws.ensure(nj * (kmax + 1) * 8) || c->j_karr.ensure(nj * nround) ||
+        c->j_ao.ensure(nj * kmax * 4) || c->j_bo.ensure(nj * kmax * 4) || c->j_wso.ensure(nj * (kmax + 1) * 8) ||
+        c->j_bic.ensure(nj * 8) || c->j_nlb.ensure(nj * 4) || c->j_lb.ensure(nj * nround * 8))
+        return 1;
+    HIPCHK(hipMemcpyAsync(c->j_utr.p, job_utr, nj * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->j_K.p, job_K, nj * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->j_fixed.p, job_fixed, nj * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->j_a.p, alpha_idx, nj * kmax * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->j_b.p, beta_idx, nj * kmax * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->j_ws.p, ws, nj * (kmax + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->j_karr.p, k_arr, nj * nround, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters.p, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->j_lb.p, 0, nj * nround * 8, c->stream));
+    const size_t lds = (size_t)c->Np_max * sizeof(double);
+    if (ev_begin(c, 2)) return 1;
+#define LAUNCH_EM(CM)                                                                                         \
+    hipLaunchKernelGGL(k_em<CM>, dim3(n_jobs), dim3(EM_THREADS), lds, c->stream, c->d_desc.as<UtrDesc>(),     \
+                       c->prm, c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),      \
+                       c->j_K.as<int32_t>(), c->j_fixed.as<int32_t>(), c->j_a.as<int32_t>(),                  \
+                       c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(),                    \
+                       c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                   \
+                       c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                   \
+                       c->d_counters.as<unsigned long long>())
+    if (kmax + 1 <= 8) LAUNCH_EM(8);
+    else if (kmax + 1 <= 16) LAUNCH_EM(16);
+    else LAUNCH_EM(32);
+#undef LAUNCH_EM
+    HIPCHK(hipGetLastError());
+    if (ev_end(c, 2)) return 1;
+    HIPCHK(hipMemcpyAsync(alpha_idx_out, c->j_ao.p, nj * kmax * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(beta_idx_out, c->j_bo.p, nj * kmax * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(ws_out, c->j_wso.p, nj * (kmax + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(bic_out, c->j_bic.p, nj * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(n_lb_out, c->j_nlb.p, nj * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(lb_out, c->j_lb.p, nj * nround * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int scape_hip_batch_labels(scape_hip_ctx *c, int32_t n_sel, int32_t kmax, const int32_t *sel_utr,
+                           const int32_t *sel_K, const int32_t *alpha_idx, const int32_t *beta_idx,
+                           const double *ws, int32_t *labels_out) {
+    if (!c) return fail("ctx is NULL");
+    if (!c->built) return fail("batch_build has not run");
+    if (n_sel < 1) return fail("n_sel < 1");
+    if (kmax < 1 || kmax > SCAPE_MAX_K) return fail("kmax out of range");
+    if (!sel_utr || !sel_K || !alpha_idx || !beta_idx || !ws || !labels_out) return fail("NULL array argument");
+    if (set_device(c)) return 1;
+    const int B = c->prm.B;
+    for (int j = 0; j < n_sel; ++j) {
+        const int u = sel_utr[j], K = sel_K[j];
+        if (u < 0 || u >= c->n_utr) return fail("labels: bad UTR index");
+        if (K < 0 || K > kmax) return fail("labels: K out of range");
+        for (int k = 0; k < K; ++k) {
+            const int a = alpha_idx[(size_t)j * kmax + k], b = beta_idx[(size_t)j * kmax + k];
+            if (a < 0 || a >= c->h_desc[u].T || b < 0 || b >= B) return fail("labels: alpha/beta index out of range");
+        }
+    }
+    const size_t ns = n_sel;
+    if (c->l_utr.ensure(ns * 4) || c->l_K.ensure(ns * 4) || c->l_a.ensure(ns * kmax * 4) || c->l_b.ensure(ns * kmax * 4) ||
+        c->l_ws.ensure(ns * (kmax + 1) * 8) || c->l_labels.ensure((size_t)c->n_bins * 4))
+        return 1;
+    HIPCHK(hipMemcpyAsync(c->l_utr.p, sel_utr, ns * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_K.p, sel_K, ns * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_a.p, alpha_idx, ns * kmax * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_b.p, beta_idx, ns * kmax * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->l_ws.p, ws, ns * (kmax + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (ev_begin(c, 3)) return 1;
+#define LAUNCH_LAB(CM)                                                                                         \
+    hipLaunchKernelGGL(k_labels<CM>, dim3(n_sel), dim3(256), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm,    \
+                       c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->l_utr.as<int32_t>(),               \
+                       c->l_K.as<int32_t>(), c->l_a.as<int32_t>(), c->l_b.as<int32_t>(), c->l_ws.as<double>(), \
+                       c->l_labels.as<int32_t>())
+    if (kmax + 1 <= 8) LAUNCH_LAB(8);
+    else if (kmax + 1 <= 16) LAUNCH_LAB(16);
+    else LAUNCH_LAB(32);
+#undef LAUNCH_LAB
+    HIPCHK(hipGetLastError());
+    if (ev_end(c, 3)) return 1;
+    for (int j = 0; j < n_sel; ++j) {
+        const UtrDesc &d = c->h_desc[sel_utr[j]];
+        HIPCHK(hipMemcpyAsync(labels_out + d.bin_off, c->l_labels.as<int32_t>() + d.bin_off, (size_t)d.N * 4,
+                              hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int scape_hip_batch_fetch_loglik(scape_hip_ctx *c, int32_t utr, double *A_out) {
+    if (!c || !A_out) return fail("NULL argument");
+    if (!c->built) return fail("batch_build has not run");
+    if (utr < 0 || utr >= c->n_utr) return fail("bad UTR index");
+    if (set_device(c)) return 1;
+    const UtrDesc &d = c->h_desc[utr];
+    std::vector<double> at((size_t)d.T * d.Np);
+    HIPCHK(hipMemcpy(at.data(), c->d_AT.as<double>() + d.at_off, at.size() * 8, hipMemcpyDeviceToHost));
+    for (int n = 0; n < d.N; ++n)
+        for (int t = 0; t < d.T; ++t) A_out[(size_t)n * d.T + t] = at[(size_t)t * d.Np + n];
+    return 0;
+}
+
+int scape_hip_batch_fetch_tensor(scape_hip_ctx *c, int32_t utr, double *M_out) {
+    if (!c || !M_out) return fail("NULL argument");
+    if (!c->built) return fail("batch_build has not run");
+    if (utr < 0 || utr >= c->n_utr) return fail("bad UTR index");
+    if (set_device(c)) return 1;
+    const UtrDesc &d = c->h_desc[utr];
+    HIPCHK(hipMemcpy2D(M_out, (size_t)d.N * 8, c->d_M.as<double>() + d.m_off, (size_t)d.Np * 8, (size_t)d.N * 8,
+                       (size_t)d.T * c->prm.B, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int scape_hip_timing_reset(scape_hip_ctx *c) {
+    if (!c) return fail("ctx is NULL");
+    if (set_device(c)) return 1;
+    if (ev_collect(c)) return 1;
+    for (int w = 0; w < 4; ++w) {
+        c->ms_acc[w] = 0;
+        c->n_acc[w] = 0;
+    }
+    return 0;
+}
+
+int scape_hip_timing_get(scape_hip_ctx *c, int32_t which, double *ms_total, int32_t *n_launches) {
+    if (!c) return fail("ctx is NULL");
+    if (which < 0 || which > 3) return fail("which out of range");
+    if (set_device(c)) return 1;
+    if (ev_collect(c)) return 1;
+    if (ms_total) *ms_total = c->ms_acc[which];
+    if (n_launches) *n_launches = c->n_acc[which];
+    return 0;
+}
+
+int scape_hip_em_counters(scape_hip_ctx *c, int64_t *rounds, int64_t *slab_elems, int64_t *z_elems) {
+    if (!c) return fail("ctx is NULL");
+    if (rounds) *rounds = (int64_t)c->h_counters[0];
+    if (slab_elems) *slab_elems = (int64_t)c->h_counters[1];
+    if (z_elems) *z_elems = (int64_t)c->h_counters[2];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+"""Batched driver of the ``infer_pa`` hot path on one MI355X.
+
+For a list of prepared UTRs it packs the ragged arrays, runs Phase A/B and the EM jobs on
+the GPU through the C-ABI and applies the reference's model selection on the host:
+``em_optim0`` (apa_core.py:846-871), the K sweep and BIC arg-min of ``run`` (:965-973),
+``rm_component`` (:832-844), labels (:976) and the re-run loop of ``subsample_run``
+(:1023-1030).  No likelihood or EM arithmetic happens here.
+
+RNG modes
+---------
+``reference``  one legacy ``RandomState(seed)`` for the whole chunk, consumed UTR by UTR in
+               the reference's order (``np.random.seed(1)``, apa_core.py:125).  Results
+               follow the reference's random stream exactly; EM jobs of one UTR run
+               together, UTRs run one after another because UTR i+1's draws depend on
+               UTR i's outcome (prune / re-run).
+``per_utr``    every UTR gets ``RandomState(seed + index)``; all UTRs of a wave advance in
+               lock-step (one launch per stage).  Statistically equivalent, fully batched.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, check, f64, i32, ptr, P_i32, P_i64, P_i8
+from .host import N_ROUND, N_TRIAL, Sampler, UtrPrep
+
+
+@dataclass
+class Fit:
+    """Result of one em_algo call on the host side (indices into the UTR's grids)."""
+    K: int
+    a_idx: np.ndarray
+    b_idx: np.ndarray
+    ws: np.ndarray
+    bic: float
+    lb: np.ndarray
+
+
+@dataclass
+class UtrResult:
+    prep: UtrPrep
+    fit: Fit = None
+    labels_bin: np.ndarray = None
+    n_jobs: int = 0
+
+
+@dataclass
+class _Job:
+    u: int              # UTR index within the loaded batch
+    K: int
+    fixed: bool
+    a_idx: np.ndarray
+    b_idx: np.ndarray
+    ws: np.ndarray
+    k_arr: np.ndarray
+
+
+class HipBatch:
+    """A batch of UTRs resident on the GPU (scape_hip_batch_* calls)."""
+
+    def __init__(self, ctx, preps):
+        self.ctx, self.lib, self.preps = ctx, ctx.lib, preps
+        p0 = preps[0]
+        for q in preps[1:]:
+            if not (np.array_equal(q.betas, p0.betas) and np.array_equal(q.s_dis, p0.s_dis)
+                    and q.p["mu_f"] == p0.p["mu_f"] and q.p["sigma_f"] == p0.p["sigma_f"]
+                    and q.p["max_unif_ws"] == p0.p["max_unif_ws"]):
+                raise ValueError("all UTRs of a batch must share the model constants")
+        if len(p0.betas) > _lib.MAX_BETA or len(p0.s_dis) > _lib.MAX_S:
+            raise ValueError("beta / polyA-length grid too long for the HIP kernels")
+        prm = Params()
+        prm.mu_f, prm.sigma_f, prm.max_unif_ws = float(p0.p["mu_f"]), float(p0.p["sigma_f"]), float(p0.p["max_unif_ws"])
+        prm.n_beta, prm.n_s, prm.nround = len(p0.betas), len(p0.s_dis), N_ROUND
+        for i, v in enumerate(p0.betas):
+            prm.betas[i] = v
+        for i, (s, q) in enumerate(zip(p0.s_dis, p0.pmf_s)):
+            prm.s_dis[i], prm.pmf_s[i] = s, q
+        self.params = prm
+        self.bin_off = np.zeros(len(preps) + 1, dtype=np.int64)
+        self.theta_off = np.zeros(len(preps) + 1, dtype=np.int64)
+        np.cumsum([q.N for q in preps], out=self.bin_off[1:])
+        np.cumsum([q.T for q in preps], out=self.theta_off[1:])
+        cat = lambda name: f64(np.concatenate([getattr(q, name) for q in preps]))
+        x, l, r, pa, cnt, th = cat("x"), cat("l"), cat("r"), cat("pa"), cat("cnt"), cat("theta")
+        Ls = f64([q.L for q in preps])
+        mt = f64([q.min_theta for q in preps])
+        ul = f64([q.unif_ll for q in preps])
+        check(self.lib.scape_hip_batch_load(self.ctx.h, ctypes.byref(prm), len(preps), ptr(self.bin_off, P_i64),
+                                            ptr(x), ptr(l), ptr(r), ptr(pa), ptr(cnt), ptr(self.theta_off, P_i64),
+                                            ptr(th), ptr(Ls), ptr(mt), ptr(ul)), "batch_load")
+        self.n_bins = int(self.bin_off[-1])
+
+    def build(self):
+        check(self.lib.scape_hip_batch_build(self.ctx.h), "batch_build")
+
+    def em(self, jobs):
+        """Run em_algo for a list of _Job; returns a list of Fit in the same order."""
+        if not jobs:
+            return []
+        n = len(jobs)
+        kmax = max(1, max(j.K for j in jobs))
+        ju = i32([j.u for j in jobs])
+        jk = i32([j.K for j in jobs])
+        jf = i32([int(j.fixed) for j in jobs])
+        a = np.zeros((n, kmax), dtype=np.int32)
+        b = np.zeros((n, kmax), dtype=np.int32)
+        w = np.zeros((n, kmax + 1), dtype=np.float64)
+        ka = np.zeros((n, N_ROUND), dtype=np.int8)
+        for i, j in enumerate(jobs):
+            a[i, :j.K], b[i, :j.K], w[i, :j.K + 1], ka[i] = j.a_idx, j.b_idx, j.ws, j.k_arr
+        ao, bo = np.zeros_like(a), np.zeros_like(b)
+        wo = np.zeros_like(w)
+        bic = np.zeros(n)
+        nlb = np.zeros(n, dtype=np.int32)
+        lb = np.zeros((n, N_ROUND))
+        check(self.lib.scape_hip_batch_em(self.ctx.h, n, kmax, ptr(ju, P_i32), ptr(jk, P_i32), ptr(jf, P_i32),
+                                          ptr(a, P_i32), ptr(b, P_i32), ptr(w), ptr(ka, P_i8),
+                                          ptr(ao, P_i32), ptr(bo, P_i32), ptr(wo), ptr(bic), ptr(nlb, P_i32),
+                                          ptr(lb)), "batch_em")
+        return [Fit(K=j.K, a_idx=ao[i, :j.K].copy(), b_idx=bo[i, :j.K].copy(), ws=wo[i, :j.K + 1].copy(),
+                    bic=float(bic[i]), lb=lb[i, :nlb[i]].copy()) for i, j in enumerate(jobs)]
+
+    def labels(self, sel):
+        """sel: list of (u, Fit) -> dict u -> int32 labels per bin (get_label, :873-881)."""
+        if not sel:
+            return {}
+        n = len(sel)
+        kmax = max(1, max(f.K for _, f in sel))
+        su = i32([u for u, _ in sel])
+        sk = i32([f.K for _, f in sel])
+        a = np.zeros((n, kmax), dtype=np.int32)
+        b = np.zeros((n, kmax), dtype=np.int32)
+        w = np.zeros((n, kmax + 1), dtype=np.float64)
+        for i, (_, f) in enumerate(sel):
+            a[i, :f.K], b[i, :f.K], w[i, :f.K + 1] = f.a_idx, f.b_idx, f.ws
+        out = np.full(self.n_bins, -1, dtype=np.int32)
+        check(self.lib.scape_hip_batch_labels(self.ctx.h, n, kmax, ptr(su, P_i32), ptr(sk, P_i32), ptr(a, P_i32),
+                                              ptr(b, P_i32), ptr(w), ptr(out, P_i32)), "batch_labels")
+        return {u: out[self.bin_off[u]:self.bin_off[u + 1]].copy() for u, _ in sel}
+
+    def fetch_loglik(self, u):
+        q = self.preps[u]
+        A = np.zeros((q.N, q.T))
+        check(self.lib.scape_hip_batch_fetch_loglik(self.ctx.h, u, ptr(A)), "fetch_loglik")
+        return A
+
+    def fetch_tensor(self, u):
+        q = self.preps[u]
+        M = np.zeros((q.T, len(q.betas), q.N))
+        check(self.lib.scape_hip_batch_fetch_tensor(self.ctx.h, u, ptr(M)), "fetch_tensor")
+        return M
+
+    def free(self):
+        check(self.lib.scape_hip_batch_free(self.ctx.h), "batch_free")
+
+
+class _Sweep:
+    """Per-UTR state machine of run() / subsample_run()'s re-run loop."""
+
+    def __init__(self, u, prep, sampler, re_run_mode, trace=None):
+        self.u, self.prep, self.sampler, self.re_run = u, prep, sampler, re_run_mode
+        self.n_max, self.n_min = prep.p["n_max_apa"], prep.p["n_min_apa"]
+        self.stage = "sweep"
+        self.best = None
+        self.done = False
+        self.n_jobs = 0
+        self.trace = trace
+
+    def make_jobs(self):
+        q = self.prep
+        jobs = []
+        if self.stage == "sweep":                       # run(): K = n_max .. n_min (:965)
+            for K in range(self.n_max, self.n_min - 1, -1):
+                for _ in range(N_TRIAL):
+                    a, b, w, ka = self.sampler.init_job(q, K)
+                    jobs.append(_Job(self.u, K, False, a, b, w, ka))
+        elif self.stage == "prune":                     # rm_component -> fixed_inference (:843, :708-711)
+            f = self.best
+            keep = np.array([i for i in range(f.K) if not f.ws[i] < q.p["min_ws"]], dtype=int)
+            Kp = len(keep)
+            w = self.sampler.init_ws(Kp, q.p["max_unif_ws"])
+            ka = self.sampler.k_arr(Kp)
+            jobs.append(_Job(self.u, Kp, True, f.a_idx[keep].astype(np.int32), f.b_idx[keep].astype(np.int32), w, ka))
+        self.n_jobs += len(jobs)
+        return jobs
+
+    def absorb(self, fits):
+        q = self.prep
+        if self.trace is not None:
+            self.trace.extend(fits)
+        if self.stage == "sweep":
+            per_k = []
+            for i in range(0, len(fits), N_TRIAL):      # em_optim0: first arg-min BIC over trials (:865)
+                grp = fits[i:i + N_TRIAL]
+                per_k.append(grp[int(np.argmin(np.array([f.bic for f in grp])))])
+            self.best = per_k[int(np.argmin(np.array([f.bic for f in per_k])))]     # (:972)
+            if any(self.best.ws[i] < q.p["min_ws"] for i in range(self.best.K)):
+                self.stage = "prune"
+                return
+        elif self.stage == "prune":
+            self.best = fits[0]
+        # re-run rule of subsample_run (:1023-1030)
+        if self.re_run and self.best.K == self.n_max:
+            self.n_min = self.n_max
+            self.n_max = self.n_max + 2
+            self.stage = "sweep"
+            return
+        self.done = True
+
+
+class Engine:
+    """infer_pa for lists of UTRs on one GPU."""
+
+    def __init__(self, device=None, mem_fraction=0.7):
+        self.ctx = _lib.default_context(device)
+        self.mem_fraction = mem_fraction
+
+    def _budget(self):
+        fb, tb, bb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(self.ctx.lib.scape_hip_batch_bytes(self.ctx.h, ctypes.byref(bb), ctypes.byref(fb), ctypes.byref(tb)),
+              "batch_bytes")
+        return int(fb.value * self.mem_fraction)
+
+    @staticmethod
+    def utr_bytes(q):
+        npad = (q.N + 15) // 16 * 16
+        return 8 * npad * q.T * (len(q.betas) + 2) + 48 * q.N
+
+    def waves(self, preps):
+        """Split into waves whose tensors fit the device (at most 65535 UTRs each)."""
+        budget = self._budget()
+        out, cur, used = [], [], 0
+        for i, q in enumerate(preps):
+            b = self.utr_bytes(q)
+            if b > budget:
+                raise _lib.ScapeHipError(f"UTR {q.gene_info_str}: marginal tensor ({b >> 20} MiB) exceeds device memory")
+            if cur and (used + b > budget or len(cur) >= 65535):
+                out.append(cur)
+                cur, used = [], 0
+            cur.append(i)
+            used += b
+        if cur:
+            out.append(cur)
+        return out
+
+    def run(self, preps, rng_mode="reference", seed=1, re_run_mode=True, rs=None, keep_trace=False):
+        """Returns a list of UtrResult (same order as preps)."""
+        if rng_mode not in ("reference", "per_utr"):
+            raise ValueError("rng_mode must be 'reference' or 'per_utr'")
+        results = [UtrResult(prep=q) for q in preps]
+        shared = Sampler(rs if rs is not None else np.random.RandomState(seed)) if rng_mode == "reference" else None
+        self.traces = [[] for _ in preps] if keep_trace else None
+        for wave in self.waves(preps):
+            batch = HipBatch(self.ctx, [preps[i] for i in wave])
+            batch.build()
+            sweeps = []
+            for u, gi in enumerate(wave):
+                smp = shared if shared is not None else Sampler(np.random.RandomState((seed + gi) % (2 ** 32)))
+                sweeps.append(_Sweep(u, preps[gi], smp, re_run_mode, self.traces[gi] if keep_trace else None))
+            if rng_mode == "reference":
+                for sw in sweeps:
+                    self._drive(batch, [sw])
+            else:
+                self._drive(batch, sweeps)
+            labs = batch.labels([(sw.u, sw.best) for sw in sweeps])
+            for sw, gi in zip(sweeps, wave):
+                results[gi].fit = sw.best
+                results[gi].labels_bin = labs[sw.u]
+                results[gi].n_jobs = sw.n_jobs
+        return results
+
+    @staticmethod
+    def _drive(batch, sweeps):
+        pending = list(sweeps)
+        while pending:
+            jobs, spans = [], []
+            for sw in pending:
+                js = sw.make_jobs()
+                spans.append((len(jobs), len(jobs) + len(js)))
+                jobs.extend(js)
+            fits = batch.em(jobs)
+            for sw, (a, b) in zip(pending, spans):
+                sw.absorb(fits[a:b])
+            pending = [sw for sw in pending if not sw.done]

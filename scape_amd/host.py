@@ -1,0 +1,215 @@
+"""Host-side (numpy) part of the ``infer_pa`` path: everything the reference does per UTR
+*around* the likelihood/EM arithmetic - read binning, grids, coverage profile, restart
+initialisation and the update order.  The arithmetic itself runs on the GPU
+(``scape_amd/csrc/scape_hip.hip``); nothing here computes likelihoods or EM updates.
+
+Citations are to the reference checkout (``/root/reference/src/scape/apa_core.py``).
+The legacy numpy ``RandomState`` calls are issued in the reference's order, so a
+``RandomState(1)`` here consumes the stream exactly like ``np.random.seed(1)`` there.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+from numpy.lib.stride_tricks import sliding_window_view
+from scipy.signal import find_peaks
+
+N_TRIAL = 10        # em_optim0: n_trial (:847)
+N_ROUND = 50        # ApaModel.nround (:422)
+
+MODEL_DEFAULTS = dict(n_max_apa=5, n_min_apa=1, utr_length=2000, min_LA=20, max_LA=150, mu_f=300,
+                      sigma_f=50, min_pa_gap=100, max_beta=70, theta_step=9, beta_step=5,
+                      min_ws=0.05, max_unif_ws=0.15)       # ApaModel.__init__ (:333-363)
+
+
+def model_params(kwargs):
+    """Overlay user keys on the ApaModel defaults; unknown keys are ignored like **kwargs (:363)."""
+    p = dict(MODEL_DEFAULTS)
+    for k in MODEL_DEFAULTS:
+        if k in kwargs and kwargs[k] is not None:
+            p[k] = kwargs[k]
+    return p
+
+
+def _labels(v, step):
+    """one column of bin_data (:296-317): NaN -> label 0, else digitize on step-wide bins"""
+    if np.all(np.isnan(v)):
+        edges = np.array([0, step])
+    else:
+        edges = np.arange(0, step + np.nanmax(v), step)
+    return np.digitize(np.where(np.isnan(v), -1.0, v), edges, right=False).astype(np.int64)
+
+
+def bin_reads(x, l, r, pa, steps=(5, 10, 10, 5)):
+    """bin_data (:285-327).  Rows of labels are packed into one int64 key whose order equals
+    the lexicographic row order np.unique(axis=0) sorts by."""
+    cols = [np.asarray(c, dtype=np.float64) for c in (x, l, r, pa)]
+    labs = [_labels(v, s) for v, s in zip(cols, steps)]
+    key = labs[0]
+    for lab in labs[1:]:
+        width = int(lab.max()) + 1
+        if int(key.max()) > (2 ** 62) // max(width, 1):
+            raise OverflowError("bin label key overflows int64")
+        key = key * width + lab
+    _, idx, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    idx = idx.reshape(-1)
+    with np.errstate(invalid="ignore"):
+        means = [np.bincount(idx, v) / cnt for v in cols]
+    return means[0], means[1], means[2], means[3], cnt.astype(np.int64), idx.astype(np.int64)
+
+
+def kernel_smooth(y, bw):
+    """ker_smooth (:680-700): Gaussian taps -3bw..3bw, edge taps renormalised."""
+    ny = len(y)
+    half = int(3 * bw)
+    w = np.exp(-np.arange(-3 * bw, 3 * bw + 1) ** 2 / (2 * bw * bw))
+    out = np.zeros_like(y, dtype=np.float64)
+    if ny > 2 * half:
+        win = sliding_window_view(y, 2 * half + 1)          # rows are y[i-half : i+half+1]
+        out[half:ny - half] = np.sum(win * w, axis=1) / np.sum(w)
+    for i in list(range(min(half, ny))) + list(range(max(ny - half, half), ny)):
+        a, b = max(i - half, 0), min(i + half, ny - 1)
+        ww = w[a - (i - half):b - (i - half) + 1]
+        out[i] = np.sum(ww * y[a:b + 1]) / np.sum(ww)
+    return out
+
+
+def coverage_profile(bx, bl, cnt, L, beta_step):
+    """_get_coverage_profile (:454-462) via a difference array (counts are integers: exact)."""
+    L = int(L)
+    diff = np.zeros(L + 1)
+    st = bx.astype(np.int64)
+    en = st + bl.astype(np.int64)
+    if en.max() > L:
+        raise IndexError("read extends beyond the UTR length")
+    np.add.at(diff, st, cnt)
+    np.add.at(diff, en, -cnt.astype(np.float64))
+    cov = np.cumsum(diff)[:L]
+    xs = np.arange(-100, L + 100)
+    ys = kernel_smooth(np.concatenate([np.zeros(100), cov, np.zeros(100)]), bw=beta_step * 3)
+    return xs, ys
+
+
+@dataclass
+class UtrPrep:
+    """Binned reads + grids of one UTR (ApaModel.__init__, :333-437)."""
+    gene_info_str: str
+    p: dict
+    x: np.ndarray
+    l: np.ndarray
+    r: np.ndarray
+    pa: np.ndarray
+    cnt: np.ndarray
+    idx: np.ndarray
+    cb_id: np.ndarray
+    read_id: np.ndarray
+    L: int
+    min_theta: float
+    theta: np.ndarray
+    betas: np.ndarray
+    s_dis: np.ndarray
+    pmf_s: np.ndarray
+    unif_ll: float
+    peaks: np.ndarray = None
+    peak_w: np.ndarray = None
+
+    @property
+    def N(self):
+        return len(self.cnt)
+
+    @property
+    def T(self):
+        return len(self.theta)
+
+
+def prepare_utr(df, gene_info_str="None", **kwargs):
+    """subsample_run head (:994-997) + ApaModel.__init__ (:333-437) + run() grids (:940-951)."""
+    p = model_params(kwargs)
+    x_raw, l_raw = np.asarray(df["x"]), np.asarray(df["l"])
+    utr_len = max(int(x_raw.max()) + int(l_raw.max()) + 50, kwargs.get("utr_length", -1) or -1)
+    bx, bl, br, bpa, cnt, idx = bin_reads(df["x"], df["l"], df["r"], df["pa"])
+    L = utr_len if utr_len > 2000 else 2000
+    if not np.all((bx >= 0) & (bx < utr_len)):
+        raise AssertionError("read start outside [0, utr_length)")            # (:388)
+    if p["n_min_apa"] > p["n_max_apa"]:
+        raise Exception("n_min_apa=" + str(p["n_min_apa"]) + " n_max_apa=" + str(p["n_max_apa"]) +
+                        ", n_max_apa has to be greater than n_min_apa!")       # (:931-933)
+    if p["max_beta"] < p["beta_step"]:
+        raise Exception("max_beta=" + str(p["max_beta"]) + " beta_step_size=" + str(p["beta_step"]) +
+                        ", max_beta has to be greater than beta_step_size!")   # (:935-937)
+    s_dis = np.arange(p["min_LA"], p["max_LA"], 10)
+    pmf = np.repeat(1 / len(s_dis), len(s_dis))
+    pmf = pmf / sum(pmf)
+    min_theta = int(min(bl)) + 0.0
+    theta = np.arange(int(min_theta), int(L), int(p["theta_step"])) + 0.0
+    betas = np.arange(p["beta_step"], p["max_beta"], p["beta_step"]) + 0.0
+    unif_ll = float(np.log((1 / L) * (1 / L) * (1 / p["max_LA"])))
+    prep = UtrPrep(gene_info_str=gene_info_str, p=p, x=bx, l=bl, r=br, pa=bpa, cnt=cnt, idx=idx,
+                   cb_id=np.array(df["cb_id"]), read_id=np.array(df["read_id"]), L=int(L),
+                   min_theta=min_theta, theta=theta, betas=betas, s_dis=s_dis.astype(np.float64),
+                   pmf_s=pmf, unif_ll=unif_ll)
+    # coverage peaks used by sample_alpha (:782-794) - data only, no RNG
+    xs, ys = coverage_profile(bx, bl, cnt, L, p["beta_step"])
+    pk, _ = find_peaks(ys, distance=p["min_pa_gap"])
+    bw = p["beta_step"] * 3
+    pw = np.array([sum(ys[i - bw:i + bw + 1]) for i in pk], dtype=np.float64)
+    prep.peaks = xs[pk]
+    prep.peak_w = pw / sum(pw) if len(pk) else pw
+    return prep
+
+
+def snap_to_grid(grid, vals):
+    """find_nearest (:535-549): nearest grid index, ties to the upper point."""
+    j = np.searchsorted(grid, vals, side="left")
+    jl = np.clip(j - 1, 0, len(grid) - 1)
+    jr = np.clip(j, 0, len(grid) - 1)
+    take_right = (vals - grid[jl]) >= (grid[jr] - vals)
+    out = np.where(j == 0, 0, np.where(j == len(grid), len(grid) - 1, np.where(take_right, jr, jl)))
+    return out.astype(np.int64)
+
+
+class Sampler:
+    """Restart initialisation and update order, drawing from a legacy RandomState in the
+    reference's call order: sample_alpha (:781-807), beta choice (:819), init_ws (:809-815),
+    gen_k_arr (:653-677)."""
+
+    def __init__(self, rs):
+        self.rs = rs
+
+    def init_ws(self, K, max_unif_ws):
+        ws = self.rs.uniform(size=(K + 1))
+        ws = ws / sum(ws)
+        if ws[-1] > max_unif_ws:
+            ws[:-1] = ws[:-1] * (1 - max_unif_ws)
+            ws[-1] = max_unif_ws
+        return ws
+
+    def k_arr(self, K, n=N_ROUND):
+        if K <= 1:
+            return np.zeros(n, dtype=np.int8)
+        arr = self.rs.permutation(K)
+        out = np.empty(n, dtype=np.int8)
+        for t0 in range(0, n, K):
+            self.rs.shuffle(arr)
+            m = min(K, n - t0)
+            out[t0:t0 + m] = arr[:m]
+        return out
+
+    def init_job(self, prep, K):
+        """init_para (:817-829) then the k_arr em_algo draws first (:720).
+        Returns (alpha_idx[K], beta_idx[K], ws[K+1], k_arr[nround])."""
+        rs, p = self.rs, prep.p
+        n_peak = len(prep.peaks)
+        if K <= n_peak:
+            res = rs.choice(prep.peaks, size=K, replace=False, p=prep.peak_w)
+        else:
+            res = rs.choice(prep.L, size=K - n_peak, replace=False)
+            res = np.concatenate((prep.peaks, res))
+        shift = np.rint(5 * p["beta_step"] * (2 * rs.uniform(low=0.0, high=1.0, size=K) - 1))
+        res = np.sort(res + shift)
+        a_idx = snap_to_grid(prep.theta, res)
+        beta = rs.choice(prep.betas, size=K, replace=True)
+        b_idx = np.searchsorted(prep.betas, beta, side="left")
+        ws = self.init_ws(K, p["max_unif_ws"])
+        return a_idx.astype(np.int32), b_idx.astype(np.int32), ws, self.k_arr(K)
