@@ -170,7 +170,15 @@ static double np_pairwise_sum(const double *a, long n) {
         return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
     }
 }
-double so_np_sum(const double *a, long n) { return np_pairwise_sum(a, n); }
+/* np.sum(a) for a 1-D contiguous array: numpy's reduction iterator hands the inner loop at most
+   8192 elements at a time (its buffer size), each piece is summed pairwise and added on */
+static double np_sum(const double *a, long n) {
+    if (n <= 8192) return np_pairwise_sum(a, n);
+    double acc = np_pairwise_sum(a, 8192);
+    for (long o = 8192; o < n; o += 8192) acc += np_pairwise_sum(a + o, (n - o < 8192) ? n - o : 8192);
+    return acc;
+}
+double so_np_sum(const double *a, long n) { return np_sum(a, n); }
 
 /* ---- EM (apa_core.py:473-573, :702-779) ------------------------------------- */
 typedef struct {
@@ -213,7 +221,7 @@ static double exp_log_lik(const so_model *m, int C, const double *logz, const do
             double z = Z[(size_t)n * C + c];
             if (z != 0) scratch[cntnz++] = (z * m->cnt[n]) * logz[(size_t)n * C + c];
         }
-    return np_pairwise_sum(scratch, cntnz);
+    return np_sum(scratch, cntnz);
 }
 
 static double elbo(const so_model *m, int C, const double *logz, const double *Z,
@@ -230,7 +238,7 @@ static double elbo(const so_model *m, int C, const double *logz, const double *Z
         }
         scratch2[n] = m->cnt[n] * np_pairwise_sum(e, C);
     }
-    return ell + np_pairwise_sum(scratch2, m->N);
+    return ell + np_sum(scratch2, m->N);
 }
 
 /*
@@ -262,7 +270,7 @@ int so_em_algo(const double *M, int T, int B, int N, const double *theta, const 
 
         /* mstep / mstep_fixed (:525-533, :552-557) */
         for (int n = 0; n < N; n++) col[n] = Z[(size_t)n * C + k];
-        if (np_pairwise_sum(col, N) < 1e-8)
+        if (np_sum(col, N) < 1e-8)
             for (int n = 0; n < N; n++) Z[(size_t)n * C + k] += 1e-8;
         /* maximize_ws (:498-505): ws = cnt @ Z ; ws /= sum */
         for (int c = 0; c < C; c++) {
@@ -290,7 +298,7 @@ int so_em_algo(const double *M, int T, int B, int N, const double *theta, const 
                     const double *row = M + ((size_t)a * B + b) * N;
                     for (int n = 0; n < N; n++)
                         scratch[n] = ((lw + row[n]) * Z[(size_t)n * C + k]) * cnt[n];
-                    double sc = np_pairwise_sum(scratch, N);
+                    double sc = np_sum(scratch, N);
                     if (!have || sc > best) { best = sc; best_a = a; best_b = b; have = 1; }
                 }
             }

@@ -71,7 +71,12 @@ def get_loglik_marginal_tensor(all_theta, predef_beta_arr, loglik_xlr_t_arr):
 def loglik_marginal_lxr(alpha, beta, all_theta, loglik_xlr_t_arr):
     """reference taichi_core.py:218-234 (one (alpha, beta) slice of the tensor)"""
     th = f64(all_theta)
+    A = f64(loglik_xlr_t_arr)
     i = int(np.searchsorted(th, alpha, side="left"))
     if i >= len(th) or th[i] != alpha:
         raise ValueError("alpha must be a point of all_theta")
-    return get_loglik_marginal_tensor(th, np.array([beta], dtype=np.float64), loglik_xlr_t_arr)[i, 0]
+    hi = int(np.searchsorted(th, alpha + 3 * beta, side="right"))      # window end (exclusive)
+    if hi > A.shape[1]:
+        raise IndexError("loglik_xlr_t_arr has fewer columns than the +-3 beta window needs")
+    # the reference only touches the window's columns, so a narrower matrix is accepted (:177-178)
+    return get_loglik_marginal_tensor(th[:A.shape[1]], np.array([beta], dtype=np.float64), A)[i, 0]

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: multi-second CPU test")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def utr_df(f, i):
+    """(gene_info_str, DataFrame) of UTR i of a fixture/trace file."""
+    cols = {c: f[f"u{i}_{c}"] for c in ["x", "l", "r", "pa", "cb_id", "read_id"]}
+    return str(f[f"u{i}_gene_info_str"]), pd.DataFrame(cols)
+
+
+def trace_params(f):
+    p = {k[6:]: f[k].item() for k in f.files if k.startswith("param_")}
+    return p
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import scape_oracle
+    scape_oracle.lib()
+    return scape_oracle
+
+
+@pytest.fixture(scope="session")
+def hip_ctx():
+    from scape_amd import _lib
+    return _lib.default_context(0)
+
+
+TRACES = ["synA", "synB", "chr17", "chr19", "toy"]
+FIXTURES = ["chr17", "chr19", "toy"]

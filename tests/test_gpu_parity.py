@@ -1,0 +1,377 @@
+"""GPU parity tests: the HIP path (through the ctypes C-ABI) against
+  - the reference's own outputs recorded in tests/golden/trace_*.npz,
+  - the CPU oracle on seeded inputs,
+  - size-independent properties at the BASELINE sizes.
+Tolerances: K / alpha / beta / labels / round counts exact; f64 values to 1e-9 relative or better
+(the north star allows 1e-4 relative on positions and weights)."""
+import math
+import os
+import pickle
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import FIXTURES, TRACES, load_npz, trace_params, utr_df
+
+pytestmark = pytest.mark.gpu
+SENT = float(np.finfo("f").min)
+
+
+def _same_sent(a, b):
+    return np.array_equal(a == SENT, b == SENT)
+
+
+# ---------------------------------------------------------------- operator level (taichi_core seam)
+def test_known_answers_through_hip():
+    """Inputs of the reference's taichi_code_test.py:514-593 pushed through the HIP operators."""
+    from scape import taichi_core as tc
+    one = lambda v: np.array([float(v)])
+    # loglik_xlr_t_pa = loglik_l_xt(x,l,theta) + logN(pa-theta; 0, sigma_f)
+    got = tc.loglik_xlr_t_pa(one(5), one(50), one(187), 70.0, 50)[0]
+    z = (187 - 70) / 50
+    assert got == pytest.approx(-math.log(65.0) - 0.5 * z * z - math.log(50) - 0.5 * math.log(2 * math.pi), rel=1e-14)
+    got = tc.loglik_xlr_t_pa(one(30), one(50), one(187), 70.0, 50)[0]          # l > theta - x
+    assert got == pytest.approx(SENT, rel=1e-15)
+    s = np.arange(20, 150, 10).astype(float)
+    pmf = np.full(13, 1 / 13)
+    # r_unknown: sum_j 1/s_j N(x; theta+s_j-mu_f, sigma_f) 1/(theta-x) pmf_j
+    x, l, th = 44.0, 50.0, 460.0
+    v = sum(1 / sj * math.exp(-0.5 * ((x - (th + sj - 300)) / 50) ** 2) / math.sqrt(2 * math.pi) / 50 / (th - x) / 13 for sj in s)
+    got = tc.loglik_xlr_t_r_unknown(one(x), one(l), None, s, pmf, th, 300, 50)[0]
+    assert got == pytest.approx(math.log(v), rel=1e-13)
+    # r_known with r=20 > s_0: first term dropped, normalised by the kept mass
+    r = 25.0
+    terms = [-math.log(sj) - 0.5 * ((x - (th + sj - 300)) / 50) ** 2 - math.log(50) - 0.5 * math.log(2 * math.pi)
+             - math.log(th - x) + math.log(1 / 13) for sj in s if sj >= r]
+    want = math.log(sum(math.exp(t - max(terms)) for t in terms)) + max(terms) - math.log(len(terms) / 13)
+    got = tc.loglik_xlr_t_r_known(one(x), one(l), one(r), s, pmf, th, 300, 50)[0]
+    assert got == pytest.approx(want, rel=1e-13)
+    # marginal on the reference's 23-point grid (alpha=37, beta=5 -> two grid points)
+    all_theta = np.arange(37, 236, 9).astype(float)
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        A = rng.rand(i + 3, i + 5)
+        got = tc.loglik_marginal_lxr(37.0, 5.0, all_theta, A)
+        g = -0.5 * ((all_theta[:2] - 37) / 5) ** 2 - math.log(5) - 0.5 * math.log(2 * math.pi)
+        want = np.log(np.exp(A[:, :2] + g - math.log(np.exp(g).sum())).sum(axis=1))
+        assert np.allclose(got, want, rtol=1e-14, atol=0)
+
+
+def test_point_kernels_vs_oracle(oracle):
+    from scape import taichi_core as tc
+    rng = np.random.default_rng(1)
+    n = 4000
+    x = rng.integers(0, 2000, n).astype(float) + rng.random(n).round(2)
+    l = rng.integers(31, 133, n).astype(float)
+    pa = x + rng.integers(40, 600, n)
+    r = rng.integers(1, 150, n).astype(float)
+    s = np.arange(20, 150, 10).astype(float)
+    pmf = rng.dirichlet(np.ones(13))
+    for theta in (1200.0, 1195.0, 1205.0, 31.0, 2500.5):
+        a, b = tc.loglik_xlr_t_pa(x, l, pa, theta, 50), oracle.loglik_xlr_t_pa(x, l, pa, theta, 50)
+        assert _same_sent(a, b) and np.allclose(a, b, rtol=1e-14, atol=0)
+        a = tc.loglik_xlr_t_r_unknown(x, l, r, s, pmf, theta, 300, 50)
+        b = oracle.loglik_xlr_t_r_unknown(x, l, r, s, pmf, theta, 300, 50)
+        assert _same_sent(a, b) and np.allclose(a, b, rtol=1e-13, atol=0)
+        a = tc.loglik_xlr_t_r_known(x, l, r, s, pmf, theta, 300, 50)
+        b = oracle.loglik_xlr_t_r_known(x, l, r, s, pmf, theta, 300, 50)
+        assert np.allclose(a, b, rtol=1e-13, atol=0)
+    assert len(tc.loglik_xlr_t_pa(x[:0], l[:0], pa[:0], 100.0, 50)) == 0      # empty input
+
+
+def test_marginal_tensor_operator_vs_oracle(oracle):
+    from scape import taichi_core as tc
+    rng = np.random.default_rng(2)
+    th = np.arange(31, 1200, 9).astype(float)
+    betas = np.arange(5, 70, 5).astype(float)
+    A = -rng.random((37, len(th))) * 700
+    A[rng.random(A.shape) < 0.3] = SENT
+    A[5] = SENT                                        # a bin that is impossible everywhere
+    got, want = tc.get_loglik_marginal_tensor(th, betas, A), oracle.get_loglik_marginal_tensor(th, betas, A)
+    assert got.shape == (len(th), 13, 37)
+    assert _same_sent(got, want) and np.allclose(got, want, rtol=1e-13, atol=0)
+    # non-uniform grid (fixed_run style, apa_core.py:895) and a single beta
+    th2 = np.unique(np.concatenate([th[:20], th[40:70], th[100:]]))
+    A2 = A[:, :len(th2)]
+    got, want = tc.get_loglik_marginal_tensor(th2, betas[3:4], A2), oracle.get_loglik_marginal_tensor(th2, betas[3:4], A2)
+    assert _same_sent(got, want) and np.allclose(got, want, rtol=1e-13, atol=0)
+
+
+# ---------------------------------------------------------------- batched build vs the reference's own tensors
+def _batch_for_trace(hip_ctx, name):
+    from scape_amd.engine import HipBatch
+    from scape_amd.host import prepare_utr
+    f = load_npz(f"trace_{name}.npz")
+    p = trace_params(f)
+    preps = []
+    for i in range(int(f["n_utr"])):
+        gene, df = utr_df(f, i)
+        preps.append(prepare_utr(df, gene_info_str=gene, **p))
+    batch = HipBatch(hip_ctx, preps)
+    batch.build()
+    return f, p, preps, batch
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_phase_a_b_vs_reference_trace(hip_ctx, name):
+    f, p, preps, batch = _batch_for_trace(hip_ctx, name)
+    for i, q in enumerate(preps):
+        A = batch.fetch_loglik(i)
+        ref = f[f"u{i}_A"]
+        assert _same_sent(A, ref) and np.allclose(A, ref, rtol=1e-13, atol=0), (name, i)
+        M = batch.fetch_tensor(i)
+        if f"u{i}_M" in f.files:
+            Mr, Mg = f[f"u{i}_M"], M
+        else:
+            Mr, Mg = f[f"u{i}_M_sel"], M[f[f"u{i}_M_rows"]]
+        assert _same_sent(Mg, Mr), (name, i)
+        # log-domain values; the linear-domain window sum differs from the reference's
+        # max-shifted logsumexp only by rounding (|M| <= ~700 -> abs error ~1e-13)
+        assert np.allclose(Mg, Mr, rtol=2e-13, atol=2e-12), (name, i, np.abs(Mg - Mr)[Mr > -1e30].max())
+        fin = M > -1e30
+        assert int((~fin).sum()) == int(f[f"u{i}_M_n_sent"])
+        assert float(M[fin].sum()) == pytest.approx(float(f[f"u{i}_M_sum_finite"]), rel=1e-11)
+    batch.free()
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_em_calls_vs_reference_trace(hip_ctx, name):
+    """Every em_algo call the reference made (inits + k_arr from the trace) re-run on the GPU."""
+    from scape_amd.engine import _Job
+    f, p, preps, batch = _batch_for_trace(hip_ctx, name)
+    jobs, meta = [], []
+    for i, q in enumerate(preps):
+        for c in range(len(f[f"u{i}_call_K"])):
+            K = int(f[f"u{i}_call_K"][c])
+            a0 = f[f"u{i}_call_a0"][c, :K]
+            a_idx = np.searchsorted(q.theta, a0).astype(np.int32)
+            assert np.array_equal(q.theta[a_idx], a0)
+            b_idx = np.searchsorted(q.betas, f[f"u{i}_call_b0"][c, :K]).astype(np.int32)
+            jobs.append(_Job(i, K, bool(f[f"u{i}_call_fixed"][c]), a_idx, b_idx, f[f"u{i}_call_w0"][c, :K + 1],
+                             f[f"u{i}_call_k_arr"][c].astype(np.int8)))
+            meta.append((i, c, K))
+    fits = batch.em(jobs)
+    n_exact = 0
+    for (i, c, K), ft in zip(meta, fits):
+        q = preps[i]
+        tag = (name, i, c, K)
+        same = (np.array_equal(q.theta[ft.a_idx], f[f"u{i}_call_a1"][c, :K])
+                and np.array_equal(q.betas[ft.b_idx], f[f"u{i}_call_b1"][c, :K])
+                and len(ft.lb) == int(f[f"u{i}_call_nlb"][c]))
+        assert same, tag
+        n_exact += same
+        assert np.allclose(ft.ws, f[f"u{i}_call_w1"][c, :K + 1], rtol=1e-9, atol=1e-13), tag
+        assert ft.bic == pytest.approx(float(f[f"u{i}_call_bic"][c]), rel=1e-10), tag
+        assert np.allclose(ft.lb, f[f"u{i}_call_lb"][c, :len(ft.lb)], rtol=1e-10), tag
+    assert n_exact == len(jobs)
+    batch.free()
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_full_pipeline_reference_stream(name):
+    """Engine in 'reference' RNG mode reproduces the reference's run of the same chunk."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    f = load_npz(f"trace_{name}.npz")
+    p = trace_params(f)
+    preps = [prepare_utr(utr_df(f, i)[1], gene_info_str=utr_df(f, i)[0], **p) for i in range(int(f["n_utr"]))]
+    eng = Engine(device=0)
+    res = eng.run(preps, rng_mode="reference", seed=int(f["seed"]), re_run_mode=bool(p["re_run_mode"]), keep_trace=True)
+    for i, r in enumerate(res):
+        para = to_parameters(r)
+        assert len(eng.traces[i]) == len(f[f"u{i}_call_K"]), (name, i)
+        assert para.K == int(f[f"u{i}_res_K"])
+        assert np.array_equal(para.alpha_arr, f[f"u{i}_res_alpha_arr"]) and para.alpha_arr.dtype == np.int64
+        assert np.array_equal(para.beta_arr, f[f"u{i}_res_beta_arr"])
+        assert np.allclose(para.ws, f[f"u{i}_res_ws"], rtol=1e-9, atol=1e-13)
+        assert para.bic == pytest.approx(float(f[f"u{i}_res_bic"]), rel=1e-10)
+        assert np.array_equal(para.label_arr, f[f"u{i}_res_label_arr"])
+        assert np.allclose(para.lb_arr, f[f"u{i}_res_lb_arr"], rtol=1e-10)
+        assert para.L == int(f[f"u{i}_L"]) and para.title == "Final Result"
+        assert np.array_equal(para.cb_id_arr, f[f"u{i}_cb_id"]) and np.array_equal(para.readID_arr, f[f"u{i}_read_id"])
+
+
+# ---------------------------------------------------------------- CLI end to end vs the committed example outputs
+@pytest.mark.parametrize("name", FIXTURES)
+def test_cli_on_example_chunks_vs_committed_goldens(tmp_path, name):
+    from click.testing import CliRunner
+    from scape.cli import cli
+    from scape_amd import safe_pickle
+    f = load_npz(f"fixture_{name}.npz")
+    out = tmp_path / "out"
+    (out / "pkl_input").mkdir(parents=True)
+    chunk = out / "pkl_input" / f"{name}.100.1.1.input.pkl"
+    with open(chunk, "wb") as fh:                       # prepare_input's append-mode layout
+        for i in range(int(f["n_utr"])):
+            gene, df = utr_df(f, i)
+            for c in ("junction", "seg1_en", "seg2_en"):
+                df[c] = 0
+            pickle.dump((gene, df), fh)
+    (out / "parameters.toml").write_text(
+        "n_max_apa = 5\nn_min_apa = 1\nmin_LA = 20\nmax_LA = 150\nmu_f = 300\nsigma_f = 50\nmin_pa_gap = 100\n"
+        "max_beta = 70\ntheta_step = 9\nbeta_step = 5\nmin_ws = 0.05\nmax_unif_ws = 0.15\nre_run_mode = true\n"
+        "fixed_run_mode = false\nutr_file = \"x.csv\"\nchunksize = 100\noutput_dir = \"ignored\"\n")
+    r = CliRunner().invoke(cli, ["infer_pa", "--pkl_input_file", str(chunk), "--output_dir", str(out)])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    res_file = out / "pkl_output" / f"{name}.100.1.1.res.pkl"
+    with open(res_file, "rb") as fh:
+        got = []
+        while True:
+            try:
+                got.append(pickle.load(fh))
+            except EOFError:
+                break
+    assert len(got) == int(f["n_utr"])
+    assert [type(g).__module__ + "." + type(g).__name__ for g in got] == ["scape.apa_core.Parameters"] * len(got)
+    assert len(safe_pickle.load_all(str(res_file))) == len(got)
+    for i, para in enumerate(got):
+        tag = (name, i)
+        assert para.gene_info_str == str(f[f"u{i}_gene_info_str"])
+        assert para.K == int(f[f"u{i}_gold_K"]) and para.L == int(f[f"u{i}_gold_L"]), tag
+        assert np.all(np.abs(para.alpha_arr - f[f"u{i}_gold_alpha_arr"]) <= 9), tag
+        assert np.mean(para.label_arr == f[f"u{i}_gold_label_arr"]) >= 0.99, tag
+        assert np.allclose(para.ws, f[f"u{i}_gold_ws"], atol=2e-2), tag
+        assert para.bic == pytest.approx(float(f[f"u{i}_gold_bic"]), rel=2e-2), tag
+        assert np.array_equal(para.cb_id_arr, f[f"u{i}_gold_cb_id_arr"])
+        assert np.array_equal(para.readID_arr, f[f"u{i}_gold_readID_arr"])
+        assert len(para.label_arr) == len(para.readID_arr)
+        assert isinstance(para.bic, np.float64) and isinstance(para.lb_arr, list)
+        assert para.label_arr.dtype == np.int64 and para.ws.dtype == np.float64
+
+
+# ---------------------------------------------------------------- batched (per_utr RNG) mode vs oracle
+def _oracle_per_utr(oracle, chunk, kw, seed):
+    out = []
+    for i, (gene, df) in enumerate(chunk):
+        np.random.seed(seed + i)
+        res, _m = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, **kw)
+        out.append(res)
+    return out
+
+
+def test_batched_mode_vs_oracle_config1(oracle):
+    """BASELINE config #2 shape (500 reads, K <= 5), a 48-UTR slice; every UTR checked."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_chunk
+    chunk = synth_chunk(48, 500, k_cap=5, base_seed=100)
+    kw = dict(n_max_apa=5, n_min_apa=1)
+    preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in chunk]
+    res = Engine(device=0).run(preps, rng_mode="per_utr", seed=7, re_run_mode=True)
+    want = _oracle_per_utr(oracle, chunk, dict(kw, re_run_mode=True), 7)
+    n_same = 0
+    for r, w in zip(res, want):
+        para = to_parameters(r)
+        same = (para.K == w.K and np.array_equal(para.alpha_arr, w.alpha_arr)
+                and np.array_equal(para.beta_arr, w.beta_arr) and np.array_equal(para.label_arr, w.label_arr))
+        n_same += same
+        if same:
+            assert np.allclose(para.ws, w.ws, rtol=1e-4, atol=1e-9)          # north-star tolerance
+            assert para.bic == pytest.approx(w.bic, rel=1e-8)
+    assert n_same == len(chunk), f"{n_same}/{len(chunk)} UTRs identical to the oracle"
+
+
+def test_edge_cases_vs_oracle(oracle, hip_ctx):
+    """tiny UTRs, all-pa reads, r-known reads, K=0 after pruning everything, duplicated reads."""
+    from scape_amd.engine import Engine, HipBatch, _Job
+    from scape_amd.host import prepare_utr
+    rng = np.random.default_rng(9)
+
+    def mk(x, l, r=None, pa=None):
+        n = len(x)
+        return pd.DataFrame({"x": np.asarray(x, dtype=np.int64), "l": np.asarray(l, dtype=np.int64),
+                             "r": np.full(n, np.nan) if r is None else r,
+                             "pa": np.full(n, np.nan) if pa is None else pa,
+                             "cb_id": np.arange(n), "read_id": np.arange(n)})
+    cases = [
+        ("one_bin", mk([400] * 120, [98] * 120)),
+        ("two_bins", mk([400] * 60 + [900] * 60, [98] * 120)),
+        ("all_pa", mk(rng.integers(300, 600, 150), rng.integers(31, 133, 150), pa=rng.integers(700, 760, 150).astype(float))),
+        ("r_known", mk(rng.integers(300, 900, 200), rng.integers(31, 133, 200), r=rng.integers(5, 140, 200).astype(float))),
+        ("long_utr", mk(rng.integers(0, 9000, 300), rng.integers(31, 133, 300))),
+    ]
+    kw = dict(n_max_apa=3, n_min_apa=1)
+    preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in cases]
+    res = Engine(device=0).run(preps, rng_mode="per_utr", seed=3, re_run_mode=True)
+    for i, ((g, df), r) in enumerate(zip(cases, res)):
+        np.random.seed(3 + i)
+        w, _m = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, re_run_mode=True, **kw)
+        q = r.prep
+        assert r.fit.K == w.K, g
+        assert np.array_equal(np.rint(q.theta[r.fit.a_idx]).astype(int), w.alpha_arr), g
+        assert np.array_equal(q.betas[r.fit.b_idx], w.beta_arr), g
+        assert np.allclose(r.fit.ws, w.ws, rtol=1e-8, atol=1e-12), g
+        assert np.array_equal(r.labels_bin.astype(np.int64)[q.idx], w.label_arr), g
+    # K = 0 fixed-inference job (rm_component can drop every component, apa_core.py:832-844)
+    batch = HipBatch(hip_ctx, preps[:1])
+    batch.build()
+    ft = batch.em([_Job(0, 0, True, np.zeros(0, np.int32), np.zeros(0, np.int32), np.array([0.15]), np.zeros(50, np.int8))])[0]
+    assert ft.K == 0 and np.allclose(ft.ws, [0.15]) and len(ft.lb) >= 2
+    lab = batch.labels([(0, ft)])[0]
+    assert np.all(lab == 0)
+    batch.free()
+
+
+def test_c_abi_error_paths(hip_ctx):
+    from scape_amd import _lib
+    from scape_amd.engine import HipBatch, _Job
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_chunk
+    g, df = synth_chunk(1, 200, base_seed=5)[0]
+    q = prepare_utr(df, gene_info_str=g)
+    batch = HipBatch(hip_ctx, [q])
+    good = _Job(0, 2, False, np.array([3, 9], np.int32), np.array([1, 2], np.int32), np.array([0.4, 0.5, 0.1]), np.zeros(50, np.int8))
+    with pytest.raises(_lib.ScapeHipError, match="batch_build"):
+        batch.em([good])                                   # EM before build
+    batch.build()
+    bad = [
+        _Job(1, 2, False, good.a_idx, good.b_idx, good.ws, good.k_arr),                       # UTR index
+        _Job(0, 2, False, np.array([3, q.T], np.int32), good.b_idx, good.ws, good.k_arr),     # alpha index
+        _Job(0, 2, False, good.a_idx, np.array([1, 13], np.int32), good.ws, good.k_arr),      # beta index
+        _Job(0, 2, False, np.array([9, 3], np.int32), good.b_idx, good.ws, good.k_arr),       # unsorted alpha
+        _Job(0, 2, False, good.a_idx, good.b_idx, good.ws, np.full(50, 2, np.int8)),          # k_arr entry
+    ]
+    for j in bad:
+        with pytest.raises(_lib.ScapeHipError):
+            batch.em([j])
+    assert batch.em([good])[0].K == 2                       # context still usable after errors
+    with pytest.raises(_lib.ScapeHipError):
+        _lib.Context(device=99)
+    batch.free()
+
+
+# ---------------------------------------------------------------- properties at the headline shape
+def test_properties_headline_shape():
+    """2k reads x K<=10 (BASELINE config #3 shape), 24 UTRs: determinism and model invariants."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    kw = dict(n_max_apa=10, n_min_apa=1)
+    items = [synth_utr(i, 2000, k_cap=10, base_seed=4242) for i in range(24)]
+    preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df, _t in items]
+    eng = Engine(device=0)
+    r1 = eng.run(preps, rng_mode="per_utr", seed=11, re_run_mode=False)
+    hits = 0
+    for i, (a, (g, df, truth)) in enumerate(zip(r1, items)):
+        pa = to_parameters(a)
+        q = a.prep
+        assert 1 <= pa.K <= 10 and len(pa.ws) == pa.K + 1 and len(pa.label_arr) == len(df)
+        assert np.all(np.diff(pa.alpha_arr) >= 0) and np.all(np.isin(pa.alpha_arr, q.theta))
+        assert np.all(np.isin(pa.beta_arr, q.betas))
+        assert np.all(pa.ws >= 0) and pa.ws[-1] <= 0.15 + 1e-12 and abs(pa.ws.sum() - 1) < 1e-9
+        assert np.all(pa.ws[:-1] >= 0.05) or pa.K == 0
+        assert np.isfinite(pa.bic) and np.all(np.isfinite(pa.lb_arr)) and 2 <= len(pa.lb_arr) <= 50
+        assert pa.label_arr.min() >= 0 and pa.label_arr.max() <= pa.K
+        # the dominant true site is recovered within 3 beta
+        k = int(np.argmax(truth["ws"]))
+        hits += bool(np.any(np.abs(pa.alpha_arr - truth["alphas"][k]) <= 3 * truth["betas"][k] + 9))
+    assert hits >= 22
+    # run-to-run determinism: identical bits
+    r3 = eng.run(preps, rng_mode="per_utr", seed=11, re_run_mode=False)
+    for a, b in zip(r1, r3):
+        assert a.fit.K == b.fit.K and np.array_equal(a.fit.a_idx, b.fit.a_idx) and np.array_equal(a.fit.b_idx, b.fit.b_idx)
+        assert np.array_equal(a.fit.ws, b.fit.ws) and a.fit.bic == b.fit.bic and np.array_equal(a.labels_bin, b.labels_bin)
