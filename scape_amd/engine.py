@@ -58,6 +58,37 @@ class _Job:
     k_arr: np.ndarray
 
 
+@dataclass
+class PackedJobs:
+    """Job tables in the C-ABI's padded layout (scape_hip_batch_em)."""
+    ju: np.ndarray          # int32 [n]      UTR index within the batch
+    jk: np.ndarray          # int32 [n]      K
+    jf: np.ndarray          # int32 [n]      fixed-inference flag
+    a: np.ndarray           # int32 [n,kmax] alpha index
+    b: np.ndarray           # int32 [n,kmax] beta index
+    w: np.ndarray           # f64   [n,kmax+1]
+    ka: np.ndarray          # int8  [n,nround]
+
+    def __len__(self):
+        return len(self.ju)
+
+    @property
+    def kmax(self):
+        return self.a.shape[1]
+
+
+def pack_jobs(jobs):
+    n = len(jobs)
+    kmax = max(1, max(j.K for j in jobs))
+    a = np.zeros((n, kmax), dtype=np.int32)
+    b = np.zeros((n, kmax), dtype=np.int32)
+    w = np.zeros((n, kmax + 1), dtype=np.float64)
+    ka = np.zeros((n, N_ROUND), dtype=np.int8)
+    for i, j in enumerate(jobs):
+        a[i, :j.K], b[i, :j.K], w[i, :j.K + 1], ka[i] = j.a_idx, j.b_idx, j.ws, j.k_arr
+    return PackedJobs(i32([j.u for j in jobs]), i32([j.K for j in jobs]), i32([int(j.fixed) for j in jobs]), a, b, w, ka)
+
+
 class HipBatch:
     """A batch of UTRs resident on the GPU (scape_hip_batch_* calls)."""
 
@@ -96,32 +127,47 @@ class HipBatch:
     def build(self):
         check(self.lib.scape_hip_batch_build(self.ctx.h), "batch_build")
 
+    def em_packed(self, pj):
+        """Run em_algo for packed job tables; returns (alpha_idx, beta_idx, ws, bic, n_lb, lb) arrays."""
+        n, kmax = len(pj), pj.kmax
+        ao, bo = np.zeros_like(pj.a), np.zeros_like(pj.b)
+        wo = np.zeros_like(pj.w)
+        bic = np.zeros(n)
+        nlb = np.zeros(n, dtype=np.int32)
+        lb = np.zeros((n, N_ROUND))
+        check(self.lib.scape_hip_batch_em(self.ctx.h, n, kmax, ptr(pj.ju, P_i32), ptr(pj.jk, P_i32),
+                                          ptr(pj.jf, P_i32), ptr(pj.a, P_i32), ptr(pj.b, P_i32), ptr(pj.w),
+                                          ptr(pj.ka, P_i8), ptr(ao, P_i32), ptr(bo, P_i32), ptr(wo), ptr(bic),
+                                          ptr(nlb, P_i32), ptr(lb)), "batch_em")
+        return ao, bo, wo, bic, nlb, lb
+
+    @staticmethod
+    def fit_at(pj, out, i):
+        ao, bo, wo, bic, nlb, lb = out
+        K = int(pj.jk[i])
+        return Fit(K=K, a_idx=ao[i, :K].copy(), b_idx=bo[i, :K].copy(), ws=wo[i, :K + 1].copy(),
+                   bic=float(bic[i]), lb=lb[i, :nlb[i]].copy())
+
     def em(self, jobs):
         """Run em_algo for a list of _Job; returns a list of Fit in the same order."""
         if not jobs:
             return []
-        n = len(jobs)
-        kmax = max(1, max(j.K for j in jobs))
-        ju = i32([j.u for j in jobs])
-        jk = i32([j.K for j in jobs])
-        jf = i32([int(j.fixed) for j in jobs])
-        a = np.zeros((n, kmax), dtype=np.int32)
-        b = np.zeros((n, kmax), dtype=np.int32)
-        w = np.zeros((n, kmax + 1), dtype=np.float64)
-        ka = np.zeros((n, N_ROUND), dtype=np.int8)
-        for i, j in enumerate(jobs):
-            a[i, :j.K], b[i, :j.K], w[i, :j.K + 1], ka[i] = j.a_idx, j.b_idx, j.ws, j.k_arr
-        ao, bo = np.zeros_like(a), np.zeros_like(b)
-        wo = np.zeros_like(w)
-        bic = np.zeros(n)
-        nlb = np.zeros(n, dtype=np.int32)
-        lb = np.zeros((n, N_ROUND))
-        check(self.lib.scape_hip_batch_em(self.ctx.h, n, kmax, ptr(ju, P_i32), ptr(jk, P_i32), ptr(jf, P_i32),
-                                          ptr(a, P_i32), ptr(b, P_i32), ptr(w), ptr(ka, P_i8),
-                                          ptr(ao, P_i32), ptr(bo, P_i32), ptr(wo), ptr(bic), ptr(nlb, P_i32),
-                                          ptr(lb)), "batch_em")
-        return [Fit(K=j.K, a_idx=ao[i, :j.K].copy(), b_idx=bo[i, :j.K].copy(), ws=wo[i, :j.K + 1].copy(),
-                    bic=float(bic[i]), lb=lb[i, :nlb[i]].copy()) for i, j in enumerate(jobs)]
+        pj = pack_jobs(jobs)
+        out = self.em_packed(pj)
+        return [self.fit_at(pj, out, i) for i in range(len(jobs))]
+
+    def timing(self, which):
+        """(sum of HIP-event durations in ms, launches) of kernel kind `which` since the last reset."""
+        ms, n = ctypes.c_double(), ctypes.c_int32()
+        check(self.lib.scape_hip_timing_get(self.ctx.h, which, ctypes.byref(ms), ctypes.byref(n)), "timing_get")
+        return ms.value, n.value
+
+    def em_counters(self):
+        """(rounds, tensor elements read by the M-step, Z elements) of the last em call."""
+        r, s, z = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(self.lib.scape_hip_em_counters(self.ctx.h, ctypes.byref(r), ctypes.byref(s), ctypes.byref(z)),
+              "em_counters")
+        return r.value, s.value, z.value
 
     def labels(self, sel):
         """sel: list of (u, Fit) -> dict u -> int32 labels per bin (get_label, :873-881)."""
@@ -202,6 +248,18 @@ class _Sweep:
                 return
         elif self.stage == "prune":
             self.best = fits[0]
+        self._after_fit()
+
+    def set_sweep_winner(self, best, n_jobs):
+        """Entry for the vectorised selection: the sweep's BIC winner is already known."""
+        self.best = best
+        self.n_jobs += n_jobs
+        if any(best.ws[i] < self.prep.p["min_ws"] for i in range(best.K)):
+            self.stage = "prune"
+            return
+        self._after_fit()
+
+    def _after_fit(self):
         # re-run rule of subsample_run (:1023-1030)
         if self.re_run and self.best.K == self.n_max:
             self.n_min = self.n_max
@@ -254,23 +312,85 @@ class Engine:
         shared = Sampler(rs if rs is not None else np.random.RandomState(seed)) if rng_mode == "reference" else None
         self.traces = [[] for _ in preps] if keep_trace else None
         for wave in self.waves(preps):
-            batch = HipBatch(self.ctx, [preps[i] for i in wave])
-            batch.build()
-            sweeps = []
-            for u, gi in enumerate(wave):
-                smp = shared if shared is not None else Sampler(np.random.RandomState((seed + gi) % (2 ** 32)))
-                sweeps.append(_Sweep(u, preps[gi], smp, re_run_mode, self.traces[gi] if keep_trace else None))
-            if rng_mode == "reference":
-                for sw in sweeps:
-                    self._drive(batch, [sw])
+            wp = [preps[i] for i in wave]
+            batch = HipBatch(self.ctx, wp)
+            if rng_mode == "reference" or keep_trace:
+                batch.build()
+                sweeps = []
+                for u, gi in enumerate(wave):
+                    smp = shared if shared is not None else Sampler(np.random.RandomState((seed + gi) % (2 ** 32)))
+                    sweeps.append(_Sweep(u, preps[gi], smp, re_run_mode, self.traces[gi] if keep_trace else None))
+                if rng_mode == "reference":
+                    for sw in sweeps:
+                        self._drive(batch, [sw])
+                else:
+                    self._drive(batch, sweeps)
+                labs = batch.labels([(sw.u, sw.best) for sw in sweeps])
+                out = [(sw.best, labs[sw.u], sw.n_jobs) for sw in sweeps]
             else:
-                self._drive(batch, sweeps)
-            labs = batch.labels([(sw.u, sw.best) for sw in sweeps])
-            for sw, gi in zip(sweeps, wave):
-                results[gi].fit = sw.best
-                results[gi].labels_bin = labs[sw.u]
-                results[gi].n_jobs = sw.n_jobs
+                plan = self.plan(wp, [(seed + gi) % (2 ** 32) for gi in wave])
+                out = self.process(batch, wp, plan, re_run_mode)
+            for (fit, lab, nj), gi in zip(out, wave):
+                results[gi].fit, results[gi].labels_bin, results[gi].n_jobs = fit, lab, nj
         return results
+
+    # ---- fully batched path (per-UTR RNG): pre-drawn job tables + vectorised selection -------------
+    @staticmethod
+    def plan(preps, seeds):
+        """Draw every restart of the first K sweep (init_para + gen_k_arr, reference order) for each
+        UTR from its own RandomState.  Returns the packed job tables plus the RNG states left
+        behind (prune / re-run draws continue from them)."""
+        jobs, samplers = [], []
+        for u, (q, sd) in enumerate(zip(preps, seeds)):
+            smp = Sampler(np.random.RandomState(sd))
+            for K in range(q.p["n_max_apa"], q.p["n_min_apa"] - 1, -1):
+                for _ in range(N_TRIAL):
+                    a, b, w, ka = smp.init_job(q, K)
+                    jobs.append(_Job(u, K, False, a, b, w, ka))
+            samplers.append(smp)
+        spans = np.zeros(len(preps) + 1, dtype=np.int64)
+        np.cumsum([(q.p["n_max_apa"] - q.p["n_min_apa"] + 1) * N_TRIAL for q in preps], out=spans[1:])
+        return dict(main=pack_jobs(jobs), spans=spans, states=[s.rs.get_state() for s in samplers])
+
+    def process(self, batch, preps, plan, re_run_mode=True):
+        """One pass of the hot path over a resident batch: Phase A/B, the main EM sweep, BIC model
+        selection, prune re-fits, re-run sweeps and labels.  Returns [(Fit, labels_bin, n_jobs)]."""
+        batch.build()
+        pj, spans = plan["main"], plan["spans"]
+        ms0 = batch.timing(2)[0]
+        out = batch.em_packed(pj)
+        self.last_main_em_ms = batch.timing(2)[0] - ms0          # HIP-event time of the sweep launch
+        self.last_main_counters = batch.em_counters()
+        bic = out[3]
+        sweeps, finished = [], {}
+        for u, q in enumerate(preps):
+            lo, hi = int(spans[u]), int(spans[u + 1])
+            nk = (hi - lo) // N_TRIAL
+            grid = bic[lo:hi].reshape(nk, N_TRIAL)
+            tb = np.argmin(grid, axis=1)                                 # em_optim0 (:865)
+            kb = int(np.argmin(grid[np.arange(nk), tb]))                 # run (:972)
+            j = lo + kb * N_TRIAL + int(tb[kb])
+            K = int(pj.jk[j])
+            ws = out[2][j, :K + 1]
+            needs_prune = bool(np.any(ws[:K] < q.p["min_ws"]))
+            needs_rerun = re_run_mode and K == q.p["n_max_apa"]
+            best = batch.fit_at(pj, out, j)
+            if not (needs_prune or needs_rerun):
+                finished[u] = (best, hi - lo)
+                continue
+            rs = np.random.RandomState(0)
+            rs.set_state(plan["states"][u])
+            sw = _Sweep(u, q, Sampler(rs), re_run_mode)
+            sw.set_sweep_winner(best, hi - lo)
+            if sw.done:
+                finished[u] = (sw.best, sw.n_jobs)
+            else:
+                sweeps.append(sw)
+        self._drive(batch, sweeps)
+        for sw in sweeps:
+            finished[sw.u] = (sw.best, sw.n_jobs)
+        labs = batch.labels([(u, finished[u][0]) for u in range(len(preps))])
+        return [(finished[u][0], labs[u], finished[u][1]) for u in range(len(preps))]
 
     @staticmethod
     def _drive(batch, sweeps):

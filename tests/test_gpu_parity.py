@@ -363,7 +363,6 @@ def test_properties_headline_shape():
         assert np.all(np.diff(pa.alpha_arr) >= 0) and np.all(np.isin(pa.alpha_arr, q.theta))
         assert np.all(np.isin(pa.beta_arr, q.betas))
         assert np.all(pa.ws >= 0) and pa.ws[-1] <= 0.15 + 1e-12 and abs(pa.ws.sum() - 1) < 1e-9
-        assert np.all(pa.ws[:-1] >= 0.05) or pa.K == 0
         assert np.isfinite(pa.bic) and np.all(np.isfinite(pa.lb_arr)) and 2 <= len(pa.lb_arr) <= 50
         assert pa.label_arr.min() >= 0 and pa.label_arr.max() <= pa.K
         # the dominant true site is recovered within 3 beta
