@@ -304,11 +304,14 @@ class Engine:
             out.append(cur)
         return out
 
-    def run(self, preps, rng_mode="reference", seed=1, re_run_mode=True, rs=None, keep_trace=False):
-        """Returns a list of UtrResult (same order as preps)."""
+    def run(self, preps, rng_mode="reference", seed=1, re_run_mode=True, rs=None, keep_trace=False, seeds=None):
+        """Returns a list of UtrResult (same order as preps).  per_utr mode: UTR i draws from
+        RandomState(seeds[i]) (default seed + i)."""
         if rng_mode not in ("reference", "per_utr"):
             raise ValueError("rng_mode must be 'reference' or 'per_utr'")
         results = [UtrResult(prep=q) for q in preps]
+        if seeds is None:
+            seeds = [(seed + i) % (2 ** 32) for i in range(len(preps))]
         shared = Sampler(rs if rs is not None else np.random.RandomState(seed)) if rng_mode == "reference" else None
         self.traces = [[] for _ in preps] if keep_trace else None
         for wave in self.waves(preps):
@@ -318,7 +321,7 @@ class Engine:
                 batch.build()
                 sweeps = []
                 for u, gi in enumerate(wave):
-                    smp = shared if shared is not None else Sampler(np.random.RandomState((seed + gi) % (2 ** 32)))
+                    smp = shared if shared is not None else Sampler(np.random.RandomState(seeds[gi]))
                     sweeps.append(_Sweep(u, preps[gi], smp, re_run_mode, self.traces[gi] if keep_trace else None))
                 if rng_mode == "reference":
                     for sw in sweeps:
@@ -328,7 +331,7 @@ class Engine:
                 labs = batch.labels([(sw.u, sw.best) for sw in sweeps])
                 out = [(sw.best, labs[sw.u], sw.n_jobs) for sw in sweeps]
             else:
-                plan = self.plan(wp, [(seed + gi) % (2 ** 32) for gi in wave])
+                plan = self.plan(wp, [seeds[gi] for gi in wave])
                 out = self.process(batch, wp, plan, re_run_mode)
             for (fit, lab, nj), gi in zip(out, wave):
                 results[gi].fit, results[gi].labels_bin, results[gi].n_jobs = fit, lab, nj
