@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -639,6 +640,8 @@ __global__ __launch_bounds__(EM_THREADS) void k_em(
     }
 }
 
+#include "em_lockstep.inc"
+
 // ------------------------------------------------------------------------------------------
 // labels: get_label (apa_core.py:873-881), one workgroup per selected model
 // ------------------------------------------------------------------------------------------
@@ -738,6 +741,9 @@ struct scape_hip_ctx {
     DevBuf d_x, d_l, d_r, d_pa, d_cnt, d_theta, d_desc, d_loglist, d_AT, d_V, d_M, d_err, d_counters;
     DevBuf j_utr, j_K, j_fixed, j_a, j_b, j_ws, j_karr, j_ao, j_bo, j_wso, j_bic, j_nlb, j_lb;
     DevBuf l_utr, l_K, l_a, l_b, l_ws, l_labels;
+    // lock-step EM state (em_lockstep.inc)
+    DevBuf e_ia, e_ib, e_sia, e_sib, e_ws, e_slw, e_lb, e_ell, e_nlb, e_status, e_rdk, e_rdlo, e_rdhi, e_rdm,
+        e_rdlw, e_rdsv, e_V, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist;
     std::vector<EventPair> ev[4];
     double ms_acc[4] = {0, 0, 0, 0};
     int n_acc[4] = {0, 0, 0, 0};
@@ -835,6 +841,92 @@ static int check_err_flag(scape_hip_ctx *c, const char *what) {
     return 0;
 }
 
+// host driver of the lock-step EM (kernels in em_lockstep.inc); job tables are already on the device
+static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *job_utr) {
+    const size_t nj = n_jobs;
+    const int nround = c->prm.nround, B = c->prm.B;
+    // host-side index tables: jobs grouped by UTR, ragged offsets of V and of the per-tile partials
+    std::vector<int64_t> ujoff(c->n_utr + 1, 0), voff(nj), ptoff(nj);
+    std::vector<int32_t> ujlist(nj);
+    for (size_t j = 0; j < nj; ++j) ujoff[job_utr[j] + 1]++;
+    for (int u = 0; u < c->n_utr; ++u) ujoff[u + 1] += ujoff[u];
+    {
+        std::vector<int64_t> fill(ujoff.begin(), ujoff.end() - 1);
+        for (size_t j = 0; j < nj; ++j) ujlist[fill[job_utr[j]]++] = (int32_t)j;
+    }
+    size_t vtot = 0, pttot = 0;
+    int tiles_max = 1;
+    for (size_t j = 0; j < nj; ++j) {
+        const UtrDesc &d = c->h_desc[job_utr[j]];
+        const int nt = (d.T * B + MT_ROWS - 1) / MT_ROWS;
+        voff[j] = (int64_t)vtot;
+        ptoff[j] = (int64_t)pttot;
+        vtot += (size_t)d.Np;
+        pttot += (size_t)nt;
+        tiles_max = std::max(tiles_max, nt);
+    }
+    if (c->e_ia.ensure(nj * kmax * 4) || c->e_ib.ensure(nj * kmax * 4) || c->e_sia.ensure(nj * kmax * 4) ||
+        c->e_sib.ensure(nj * kmax * 4) || c->e_ws.ensure(nj * (kmax + 1) * 8) || c->e_slw.ensure(nj * (kmax + 1) * 8) ||
+        c->e_lb.ensure(nj * 8) || c->e_ell.ensure(nj * 8) || c->e_nlb.ensure(nj * 4) || c->e_status.ensure(nj * 4) ||
+        c->e_rdk.ensure(nj * 4) || c->e_rdlo.ensure(nj * 4) || c->e_rdhi.ensure(nj * 4) || c->e_rdm.ensure(nj * 4) ||
+        c->e_rdlw.ensure(nj * 8) || c->e_rdsv.ensure(nj * 8) || c->e_V.ensure(vtot * 8) || c->e_voff.ensure(nj * 8) ||
+        c->e_ptscore.ensure(pttot * 8) || c->e_ptrow.ensure(pttot * 4) || c->e_ptoff.ensure(nj * 8) ||
+        c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4))
+        return 1;
+    HIPCHK(hipMemcpyAsync(c->e_voff.p, voff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->e_ptoff.p, ptoff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->e_ujoff.p, ujoff.data(), (c->n_utr + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->e_ujlist.p, ujlist.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+    EmState S;
+    S.ia = c->e_ia.as<int32_t>();
+    S.ib = c->e_ib.as<int32_t>();
+    S.sia = c->e_sia.as<int32_t>();
+    S.sib = c->e_sib.as<int32_t>();
+    S.ws = c->e_ws.as<double>();
+    S.slw = c->e_slw.as<double>();
+    S.lb = c->e_lb.as<double>();
+    S.ell = c->e_ell.as<double>();
+    S.nlb = c->e_nlb.as<int32_t>();
+    S.status = c->e_status.as<int32_t>();
+    S.rd_k = c->e_rdk.as<int32_t>();
+    S.rd_lo = c->e_rdlo.as<int32_t>();
+    S.rd_hi = c->e_rdhi.as<int32_t>();
+    S.rd_m = c->e_rdm.as<int32_t>();
+    S.rd_lw = c->e_rdlw.as<double>();
+    S.rd_sv = c->e_rdsv.as<double>();
+    S.V = c->e_V.as<double>();
+    S.voff = c->e_voff.as<int64_t>();
+    S.pt_score = c->e_ptscore.as<double>();
+    S.pt_row = c->e_ptrow.as<int32_t>();
+    S.ptoff = c->e_ptoff.as<int64_t>();
+    for (int r = 0; r <= nround; ++r) {
+#define LAUNCH_E(CM)                                                                                           \
+    hipLaunchKernelGGL(k2_estep<CM>, dim3(n_jobs), dim3(64), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm,    \
+                       c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),               \
+                       c->j_K.as<int32_t>(), c->j_fixed.as<int32_t>(), c->j_a.as<int32_t>(),                   \
+                       c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(), S,                  \
+                       c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                    \
+                       c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                    \
+                       c->d_counters.as<unsigned long long>(), r)
+        if (kmax + 1 <= 4) LAUNCH_E(4);
+        else if (kmax + 1 <= 8) LAUNCH_E(8);
+        else if (kmax + 1 <= 12) LAUNCH_E(12);
+        else if (kmax + 1 <= 16) LAUNCH_E(16);
+        else if (kmax + 1 <= 24) LAUNCH_E(24);
+        else LAUNCH_E(32);
+#undef LAUNCH_E
+        HIPCHK(hipGetLastError());
+        if (r < nround) {
+            hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((c->n_utr + 7) / 8) * 8 * tiles_max)), dim3(256), 0, c->stream,
+                               c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->n_utr, tiles_max, c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.voff,
+                               S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw, S.rd_sv, S.ptoff, S.pt_score, S.pt_row);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
 extern "C" {
 
 int scape_hip_abi_version(void) { return SCAPE_HIP_ABI_VERSION; }
@@ -875,7 +967,10 @@ int scape_hip_batch_free(scape_hip_ctx *c) {
     DevBuf *all[] = {&c->d_x, &c->d_l, &c->d_r, &c->d_pa, &c->d_cnt, &c->d_theta, &c->d_desc, &c->d_loglist,
                      &c->d_AT, &c->d_V, &c->d_M, &c->j_utr, &c->j_K, &c->j_fixed, &c->j_a, &c->j_b, &c->j_ws,
                      &c->j_karr, &c->j_ao, &c->j_bo, &c->j_wso, &c->j_bic, &c->j_nlb, &c->j_lb, &c->l_utr,
-                     &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels};
+                     &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels, &c->e_ia, &c->e_ib, &c->e_sia, &c->e_sib,
+                     &c->e_ws, &c->e_slw, &c->e_lb, &c->e_ell, &c->e_nlb, &c->e_status, &c->e_rdk, &c->e_rdlo,
+                     &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_V, &c->e_voff, &c->e_ptscore,
+                     &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist};
     for (DevBuf *b : all) b->release();
     c->loaded = c->built = false;
     c->n_utr = 0;
@@ -1176,8 +1271,11 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipMemcpyAsync(c->j_karr.p, k_arr, nj * nround, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_counters.p, 0, 3 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->j_lb.p, 0, nj * nround * 8, c->stream));
-    const size_t lds = (size_t)c->Np_max * sizeof(double);
+    const char *mode = getenv("SCAPE_HIP_EM");
+    const bool use_v1 = mode && strcmp(mode, "v1") == 0;
     if (ev_begin(c, 2)) return 1;
+    if (use_v1) {
+        const size_t lds = (size_t)c->Np_max * sizeof(double);
 #define LAUNCH_EM(CM)                                                                                         \
     hipLaunchKernelGGL(k_em<CM>, dim3(n_jobs), dim3(EM_THREADS), lds, c->stream, c->d_desc.as<UtrDesc>(),     \
                        c->prm, c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),      \
@@ -1186,11 +1284,14 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
                        c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                   \
                        c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                   \
                        c->d_counters.as<unsigned long long>())
-    if (kmax + 1 <= 8) LAUNCH_EM(8);
-    else if (kmax + 1 <= 16) LAUNCH_EM(16);
-    else LAUNCH_EM(32);
+        if (kmax + 1 <= 8) LAUNCH_EM(8);
+        else if (kmax + 1 <= 16) LAUNCH_EM(16);
+        else LAUNCH_EM(32);
 #undef LAUNCH_EM
-    HIPCHK(hipGetLastError());
+        HIPCHK(hipGetLastError());
+    } else {
+        if (em_lockstep(c, n_jobs, kmax, job_utr)) return 1;
+    }
     if (ev_end(c, 2)) return 1;
     HIPCHK(hipMemcpyAsync(alpha_idx_out, c->j_ao.p, nj * kmax * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(beta_idx_out, c->j_bo.p, nj * kmax * 4, hipMemcpyDeviceToHost, c->stream));
