@@ -127,8 +127,10 @@ int scape_hip_batch_free(scape_hip_ctx *ctx);
 
 /*
  * Kernel timing measured with HIP events on the stream the kernels are launched on.
- * which: 0 = Phase A, 1 = Phase B, 2 = EM, 3 = labels.  Returns the sum of the durations and the
- * number of launches since the last scape_hip_timing_reset().
+ * which: 0 = Phase A, 1 = Phase B, 2 = EM (one whole scape_hip_batch_em call), 3 = labels,
+ * 4 = the per-round E-step kernel, 5 = the per-round M-step kernel (4 and 5 are recorded only when the
+ * environment variable SCAPE_HIP_ROUND_TIMING is set).  Returns the sum of the durations and the number
+ * of launches since the last scape_hip_timing_reset().
  */
 int scape_hip_timing_reset(scape_hip_ctx *ctx);
 int scape_hip_timing_get(scape_hip_ctx *ctx, int32_t which, double *ms_total, int32_t *n_launches);

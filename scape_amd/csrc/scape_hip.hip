@@ -743,10 +743,10 @@ struct scape_hip_ctx {
     DevBuf l_utr, l_K, l_a, l_b, l_ws, l_labels;
     // lock-step EM state (em_lockstep.inc)
     DevBuf e_ia, e_ib, e_sia, e_sib, e_ws, e_slw, e_lb, e_ell, e_nlb, e_status, e_rdk, e_rdlo, e_rdhi, e_rdm,
-        e_rdlw, e_rdsv, e_V, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist;
-    std::vector<EventPair> ev[4];
-    double ms_acc[4] = {0, 0, 0, 0};
-    int n_acc[4] = {0, 0, 0, 0};
+        e_rdlw, e_rdsv, e_rdn0, e_rdn1, e_V, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist;
+    std::vector<EventPair> ev[6];
+    double ms_acc[6] = {0, 0, 0, 0, 0, 0};
+    int n_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long h_counters[3] = {0, 0, 0};
 };
 
@@ -764,7 +764,7 @@ static int ev_end(scape_hip_ctx *c, int which) {
 }
 static int ev_collect(scape_hip_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 6; ++w) {
         for (auto &e : c->ev[w]) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
@@ -869,7 +869,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         c->e_sib.ensure(nj * kmax * 4) || c->e_ws.ensure(nj * (kmax + 1) * 8) || c->e_slw.ensure(nj * (kmax + 1) * 8) ||
         c->e_lb.ensure(nj * 8) || c->e_ell.ensure(nj * 8) || c->e_nlb.ensure(nj * 4) || c->e_status.ensure(nj * 4) ||
         c->e_rdk.ensure(nj * 4) || c->e_rdlo.ensure(nj * 4) || c->e_rdhi.ensure(nj * 4) || c->e_rdm.ensure(nj * 4) ||
-        c->e_rdlw.ensure(nj * 8) || c->e_rdsv.ensure(nj * 8) || c->e_V.ensure(vtot * 8) || c->e_voff.ensure(nj * 8) ||
+        c->e_rdlw.ensure(nj * 8) || c->e_rdsv.ensure(nj * 8) || c->e_rdn0.ensure(nj * 4) || c->e_rdn1.ensure(nj * 4) || c->e_V.ensure(vtot * 8) || c->e_voff.ensure(nj * 8) ||
         c->e_ptscore.ensure(pttot * 8) || c->e_ptrow.ensure(pttot * 4) || c->e_ptoff.ensure(nj * 8) ||
         c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4))
         return 1;
@@ -895,12 +895,22 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     S.rd_m = c->e_rdm.as<int32_t>();
     S.rd_lw = c->e_rdlw.as<double>();
     S.rd_sv = c->e_rdsv.as<double>();
+    S.rd_n0 = c->e_rdn0.as<int32_t>();
+    S.rd_n1 = c->e_rdn1.as<int32_t>();
     S.V = c->e_V.as<double>();
     S.voff = c->e_voff.as<int64_t>();
     S.pt_score = c->e_ptscore.as<double>();
     S.pt_row = c->e_ptrow.as<int32_t>();
     S.ptoff = c->e_ptoff.as<int64_t>();
+    unsigned long long *dbg = nullptr;
+    const bool debug = getenv("SCAPE_HIP_DEBUG") != nullptr;
+    if (debug) {
+        HIPCHK(hipMalloc((void **)&dbg, 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
+    }
+    const bool fine = getenv("SCAPE_HIP_ROUND_TIMING") != nullptr;
     for (int r = 0; r <= nround; ++r) {
+        if (fine && ev_begin(c, 4)) return 1;
 #define LAUNCH_E(CM)                                                                                           \
     hipLaunchKernelGGL(k2_estep<CM>, dim3(n_jobs), dim3(64), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm,    \
                        c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),               \
@@ -917,13 +927,25 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         else LAUNCH_E(32);
 #undef LAUNCH_E
         HIPCHK(hipGetLastError());
+        if (fine && ev_end(c, 4)) return 1;
         if (r < nround) {
+            if (fine && ev_begin(c, 5)) return 1;
             hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((c->n_utr + 7) / 8) * 8 * tiles_max)), dim3(256), 0, c->stream,
                                c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->n_utr, tiles_max, c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.voff,
-                               S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw, S.rd_sv, S.ptoff, S.pt_score, S.pt_row);
+                               S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, dbg);
             HIPCHK(hipGetLastError());
+            if (fine && ev_end(c, 5)) return 1;
+        }
+        if (debug && (r == 0 || r == 10 || r == 25 || r == nround - 1)) {
+            unsigned long long h[16];
+            HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[em round %d] tiles %llu active %llu sum_cnt %llu passes %llu | G-hist:", r, h[0], h[1], h[2], h[3]);
+            for (int i = 4; i < 16; ++i) fprintf(stderr, " %llu", h[i]);
+            fprintf(stderr, "\n");
+            HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
         }
     }
+    if (dbg) (void)hipFree(dbg);
     return 0;
 }
 
@@ -969,7 +991,7 @@ int scape_hip_batch_free(scape_hip_ctx *c) {
                      &c->j_karr, &c->j_ao, &c->j_bo, &c->j_wso, &c->j_bic, &c->j_nlb, &c->j_lb, &c->l_utr,
                      &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels, &c->e_ia, &c->e_ib, &c->e_sia, &c->e_sib,
                      &c->e_ws, &c->e_slw, &c->e_lb, &c->e_ell, &c->e_nlb, &c->e_status, &c->e_rdk, &c->e_rdlo,
-                     &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_V, &c->e_voff, &c->e_ptscore,
+                     &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_rdn0, &c->e_rdn1, &c->e_V, &c->e_voff, &c->e_ptscore,
                      &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist};
     for (DevBuf *b : all) b->release();
     c->loaded = c->built = false;
@@ -984,7 +1006,7 @@ int scape_hip_destroy(scape_hip_ctx *c) {
     scape_hip_batch_free(c);
     c->d_err.release();
     c->d_counters.release();
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < 6; ++w)
         for (auto &e : c->ev[w]) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
@@ -1381,7 +1403,7 @@ int scape_hip_timing_reset(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
     if (set_device(c)) return 1;
     if (ev_collect(c)) return 1;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 6; ++w) {
         c->ms_acc[w] = 0;
         c->n_acc[w] = 0;
     }
@@ -1390,7 +1412,7 @@ int scape_hip_timing_reset(scape_hip_ctx *c) {
 
 int scape_hip_timing_get(scape_hip_ctx *c, int32_t which, double *ms_total, int32_t *n_launches) {
     if (!c) return fail("ctx is NULL");
-    if (which < 0 || which > 3) return fail("which out of range");
+    if (which < 0 || which > 5) return fail("which out of range");
     if (set_device(c)) return 1;
     if (ev_collect(c)) return 1;
     if (ms_total) *ms_total = c->ms_acc[which];

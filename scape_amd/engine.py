@@ -187,6 +187,15 @@ class HipBatch:
                                               ptr(b, P_i32), ptr(w), ptr(out, P_i32)), "batch_labels")
         return {u: out[self.bin_off[u]:self.bin_off[u + 1]].copy() for u, _ in sel}
 
+    def labels_packed(self, su, sk, a, b, w):
+        """get_label for models given as padded tables; returns the flat int32 label array of the batch."""
+        su, sk, a, b = i32(su), i32(sk), i32(a), i32(b)
+        w = f64(w)
+        out = np.full(self.n_bins, -1, dtype=np.int32)
+        check(self.lib.scape_hip_batch_labels(self.ctx.h, len(su), a.shape[1], ptr(su, P_i32), ptr(sk, P_i32),
+                                              ptr(a, P_i32), ptr(b, P_i32), ptr(w), ptr(out, P_i32)), "batch_labels")
+        return out
+
     def fetch_loglik(self, u):
         q = self.preps[u]
         A = np.zeros((q.N, q.T))
@@ -358,42 +367,82 @@ class Engine:
     def process(self, batch, preps, plan, re_run_mode=True):
         """One pass of the hot path over a resident batch: Phase A/B, the main EM sweep, BIC model
         selection, prune re-fits, re-run sweeps and labels.  Returns [(Fit, labels_bin, n_jobs)]."""
+        from time import perf_counter as _now
+        t0 = _now()
         batch.build()
         pj, spans = plan["main"], plan["spans"]
         ms0 = batch.timing(2)[0]
         out = batch.em_packed(pj)
         self.last_main_em_ms = batch.timing(2)[0] - ms0          # HIP-event time of the sweep launch
         self.last_main_counters = batch.em_counters()
-        bic = out[3]
-        sweeps, finished = [], {}
-        for u, q in enumerate(preps):
-            lo, hi = int(spans[u]), int(spans[u + 1])
-            nk = (hi - lo) // N_TRIAL
-            grid = bic[lo:hi].reshape(nk, N_TRIAL)
-            tb = np.argmin(grid, axis=1)                                 # em_optim0 (:865)
-            kb = int(np.argmin(grid[np.arange(nk), tb]))                 # run (:972)
-            j = lo + kb * N_TRIAL + int(tb[kb])
-            K = int(pj.jk[j])
-            ws = out[2][j, :K + 1]
-            needs_prune = bool(np.any(ws[:K] < q.p["min_ws"]))
-            needs_rerun = re_run_mode and K == q.p["n_max_apa"]
-            best = batch.fit_at(pj, out, j)
-            if not (needs_prune or needs_rerun):
-                finished[u] = (best, hi - lo)
-                continue
+        t1 = _now()
+        ao, bo, wo, bic, nlb, lb = out
+        U = len(preps)
+        # ---- em_optim0 (:865) + run (:972): first arg-min BIC over restarts, then over K (desc) ----
+        njobs = np.diff(spans)
+        if np.all(njobs == njobs[0]):
+            nk = int(njobs[0]) // N_TRIAL
+            grid = bic.reshape(U, nk, N_TRIAL)
+            tb = np.argmin(grid, axis=2)
+            kb = np.argmin(np.take_along_axis(grid, tb[:, :, None], axis=2)[:, :, 0], axis=1)
+            win = spans[:-1] + kb * N_TRIAL + tb[np.arange(U), kb]
+        else:
+            win = np.zeros(U, dtype=np.int64)
+            for u in range(U):
+                lo, hi = int(spans[u]), int(spans[u + 1])
+                g = bic[lo:hi].reshape(-1, N_TRIAL)
+                tbu = np.argmin(g, axis=1)
+                kbu = int(np.argmin(g[np.arange(len(tbu)), tbu]))
+                win[u] = lo + kbu * N_TRIAL + int(tbu[kbu])
+        Kw = pj.jk[win].astype(np.int64)
+        min_ws = np.array([q.p["min_ws"] for q in preps])
+        n_max = np.array([q.p["n_max_apa"] for q in preps])
+        comp = np.arange(pj.kmax)[None, :] < Kw[:, None]
+        needs_prune = np.any((wo[win, :pj.kmax] < min_ws[:, None]) & comp, axis=1)
+        needs_more = needs_prune | (re_run_mode & (Kw == n_max))
+        fits = [None] * U
+        njob_out = njobs.astype(np.int64).copy()
+        sweeps = []
+        for u in np.nonzero(needs_more)[0]:
+            u = int(u)
             rs = np.random.RandomState(0)
             rs.set_state(plan["states"][u])
-            sw = _Sweep(u, q, Sampler(rs), re_run_mode)
-            sw.set_sweep_winner(best, hi - lo)
+            sw = _Sweep(u, preps[u], Sampler(rs), re_run_mode)
+            sw.set_sweep_winner(batch.fit_at(pj, out, int(win[u])), int(njobs[u]))
             if sw.done:
-                finished[u] = (sw.best, sw.n_jobs)
+                fits[u], njob_out[u] = sw.best, sw.n_jobs
             else:
                 sweeps.append(sw)
         self._drive(batch, sweeps)
         for sw in sweeps:
-            finished[sw.u] = (sw.best, sw.n_jobs)
-        labs = batch.labels([(u, finished[u][0]) for u in range(len(preps))])
-        return [(finished[u][0], labs[u], finished[u][1]) for u in range(len(preps))]
+            fits[sw.u], njob_out[sw.u] = sw.best, sw.n_jobs
+        t2 = _now()
+        # ---- labels for every UTR (get_label, :873-881) -------------------------------------------
+        kmax_f = max(1, int(Kw.max()), max((f.K for f in fits if f is not None), default=1))
+        la = np.zeros((U, kmax_f), dtype=np.int32)
+        lbi = np.zeros((U, kmax_f), dtype=np.int32)
+        lw = np.zeros((U, kmax_f + 1), dtype=np.float64)
+        lk = Kw.astype(np.int32).copy()
+        m = min(kmax_f, pj.kmax)
+        la[:, :m], lbi[:, :m] = ao[win, :m], bo[win, :m]
+        lw[:, :m + 1] = wo[win, :m + 1]
+        for u, f in enumerate(fits):
+            if f is not None:
+                lk[u] = f.K
+                la[u], lbi[u], lw[u] = 0, 0, 0.0
+                la[u, :f.K], lbi[u, :f.K], lw[u, :f.K + 1] = f.a_idx, f.b_idx, f.ws
+        la[la < 0] = 0
+        lbi[lbi < 0] = 0
+        flat = batch.labels_packed(np.arange(U, dtype=np.int32), lk, la, lbi, lw)
+        t3 = _now()
+        res = []
+        for u in range(U):
+            f = fits[u] if fits[u] is not None else batch.fit_at(pj, out, int(win[u]))
+            res.append((f, flat[batch.bin_off[u]:batch.bin_off[u + 1]], int(njob_out[u])))
+        t4 = _now()
+        self.last_host_ms = dict(build_em=(t1 - t0) * 1e3, select_prune=(t2 - t1) * 1e3, labels=(t3 - t2) * 1e3,
+                                 collect=(t4 - t3) * 1e3)
+        return res
 
     @staticmethod
     def _drive(batch, sweeps):
