@@ -842,7 +842,7 @@ static int check_err_flag(scape_hip_ctx *c, const char *what) {
 }
 
 // host driver of the lock-step EM (kernels in em_lockstep.inc); job tables are already on the device
-static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *job_utr) {
+static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *job_utr, const int32_t *job_fixed) {
     const size_t nj = n_jobs;
     const int nround = c->prm.nround, B = c->prm.B;
     // host-side index tables: jobs grouped by UTR, ragged offsets of V and of the per-tile partials
@@ -909,6 +909,9 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
     }
     const bool fine = getenv("SCAPE_HIP_ROUND_TIMING") != nullptr;
+    bool any_m = false;   // fixed-inference jobs (mstep_fixed) have no grid arg-max
+    for (size_t j = 0; j < nj && !any_m; ++j) any_m = job_fixed[j] == 0;
+    unsigned long long executed_prev = 0;
     for (int r = 0; r <= nround; ++r) {
         if (fine && ev_begin(c, 4)) return 1;
 #define LAUNCH_E(CM)                                                                                           \
@@ -928,13 +931,22 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
 #undef LAUNCH_E
         HIPCHK(hipGetLastError());
         if (fine && ev_end(c, 4)) return 1;
-        if (r < nround) {
+        if (r < nround && any_m) {
             if (fine && ev_begin(c, 5)) return 1;
             hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((c->n_utr + 7) / 8) * 8 * tiles_max)), dim3(256), 0, c->stream,
                                c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->n_utr, tiles_max, c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.voff,
                                S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, dbg);
             HIPCHK(hipGetLastError());
             if (fine && ev_end(c, 5)) return 1;
+        }
+        if (r < nround && (r & 3) == 3) {
+            // early exit: no job executed a round since the last probe -> every job has been finalised
+            unsigned long long executed = 0;
+            HIPCHK(hipMemcpyAsync(&executed, c->d_counters.as<unsigned long long>() + 3, sizeof(executed),
+                                  hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (executed == executed_prev) break;
+            executed_prev = executed;
         }
         if (debug && (r == 0 || r == 10 || r == 25 || r == nround - 1)) {
             unsigned long long h[16];
@@ -972,7 +984,7 @@ int scape_hip_create(int device, scape_hip_ctx **out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     HIPCHK(hipStreamCreate(&c->stream));
-    if (c->d_counters.ensure(3 * sizeof(unsigned long long))) return 1;
+    if (c->d_counters.ensure(4 * sizeof(unsigned long long))) return 1;
     *out = c;
     return 0;
 }
@@ -1291,7 +1303,7 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipMemcpyAsync(c->j_b.p, beta_idx, nj * kmax * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->j_ws.p, ws, nj * (kmax + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->j_karr.p, k_arr, nj * nround, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_counters.p, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->j_lb.p, 0, nj * nround * 8, c->stream));
     const char *mode = getenv("SCAPE_HIP_EM");
     const bool use_v1 = mode && strcmp(mode, "v1") == 0;
@@ -1312,7 +1324,7 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
 #undef LAUNCH_EM
         HIPCHK(hipGetLastError());
     } else {
-        if (em_lockstep(c, n_jobs, kmax, job_utr)) return 1;
+        if (em_lockstep(c, n_jobs, kmax, job_utr, job_fixed)) return 1;
     }
     if (ev_end(c, 2)) return 1;
     HIPCHK(hipMemcpyAsync(alpha_idx_out, c->j_ao.p, nj * kmax * 4, hipMemcpyDeviceToHost, c->stream));

@@ -362,7 +362,23 @@ class Engine:
             samplers.append(smp)
         spans = np.zeros(len(preps) + 1, dtype=np.int64)
         np.cumsum([(q.p["n_max_apa"] - q.p["n_min_apa"] + 1) * N_TRIAL for q in preps], out=spans[1:])
-        return dict(main=pack_jobs(jobs), spans=spans, states=[s.rs.get_state() for s in samplers])
+        states = [s.rs.get_state() for s in samplers]
+        # rm_component draws (init_ws + gen_k_arr, :843 -> :709 -> :720) for every possible K' < n_max,
+        # each continuing the UTR's stream from the state the sweep left behind
+        kcap = max(q.p["n_max_apa"] for q in preps)
+        prune_w = np.zeros((len(preps), kcap, kcap + 1))
+        prune_ka = np.zeros((len(preps), kcap, N_ROUND), dtype=np.int8)
+        prune_states = [[None] * kcap for _ in preps]
+        rs = np.random.RandomState(0)
+        for u, q in enumerate(preps):
+            for Kp in range(q.p["n_max_apa"]):
+                rs.set_state(states[u])
+                smp = Sampler(rs)
+                prune_w[u, Kp, :Kp + 1] = smp.init_ws(Kp, q.p["max_unif_ws"])
+                prune_ka[u, Kp] = smp.k_arr(Kp)
+                prune_states[u][Kp] = rs.get_state()
+        return dict(main=pack_jobs(jobs), spans=spans, states=states, prune_w=prune_w, prune_ka=prune_ka,
+                    prune_states=prune_states)
 
     def process(self, batch, preps, plan, re_run_mode=True):
         """One pass of the hot path over a resident batch: Phase A/B, the main EM sweep, BIC model
@@ -399,23 +415,51 @@ class Engine:
         n_max = np.array([q.p["n_max_apa"] for q in preps])
         comp = np.arange(pj.kmax)[None, :] < Kw[:, None]
         needs_prune = np.any((wo[win, :pj.kmax] < min_ws[:, None]) & comp, axis=1)
-        needs_more = needs_prune | (re_run_mode & (Kw == n_max))
         fits = [None] * U
         njob_out = njobs.astype(np.int64).copy()
+        # ---- rm_component (:832-844): ws-only re-fit of the kept components, all pruned UTRs in one launch
+        pu = np.nonzero(needs_prune)[0]
+        refit = {}
+        if len(pu):
+            keep = comp[pu] & ~(wo[win[pu], :pj.kmax] < min_ws[pu, None])
+            Kp = keep.sum(axis=1)
+            order = np.argsort(~keep, axis=1, kind="stable")              # kept components first, in order
+            kmp = max(1, int(Kp.max()))
+            sel = np.arange(kmp)[None, :] < Kp[:, None]
+            ra = np.where(sel, np.take_along_axis(ao[win[pu]], order, axis=1)[:, :kmp], 0).astype(np.int32)
+            rb = np.where(sel, np.take_along_axis(bo[win[pu]], order, axis=1)[:, :kmp], 0).astype(np.int32)
+            rw = np.ascontiguousarray(plan["prune_w"][pu, Kp, :kmp + 1])
+            rka = np.ascontiguousarray(plan["prune_ka"][pu, Kp])
+            rpj = PackedJobs(i32(pu), i32(Kp), np.ones(len(pu), dtype=np.int32), ra, rb, rw, rka)
+            rout = batch.em_packed(rpj)
+            njob_out[pu] += 1
+            for i, u in enumerate(pu):
+                refit[int(u)] = (rpj, rout, i)
+        # ---- re-run rule (:1023-1030): K hit the cap -> continue that UTR with the generic state machine
         sweeps = []
-        for u in np.nonzero(needs_more)[0]:
-            u = int(u)
-            rs = np.random.RandomState(0)
-            rs.set_state(plan["states"][u])
-            sw = _Sweep(u, preps[u], Sampler(rs), re_run_mode)
-            sw.set_sweep_winner(batch.fit_at(pj, out, int(win[u])), int(njobs[u]))
-            if sw.done:
-                fits[u], njob_out[u] = sw.best, sw.n_jobs
-            else:
+        if re_run_mode:
+            Kfin = Kw.copy()
+            if len(pu):
+                Kfin[pu] = Kp
+            for u in np.nonzero(Kfin == n_max)[0]:
+                u = int(u)
+                rs = np.random.RandomState(0)
+                if u in refit:
+                    rpj, rout, i = refit.pop(u)
+                    best = batch.fit_at(rpj, rout, i)
+                    rs.set_state(plan["prune_states"][u][best.K])
+                else:
+                    best = batch.fit_at(pj, out, int(win[u]))
+                    rs.set_state(plan["states"][u])
+                sw = _Sweep(u, preps[u], Sampler(rs), re_run_mode)
+                sw.best, sw.n_jobs = best, int(njob_out[u])
+                sw._after_fit()
                 sweeps.append(sw)
-        self._drive(batch, sweeps)
-        for sw in sweeps:
-            fits[sw.u], njob_out[sw.u] = sw.best, sw.n_jobs
+            self._drive(batch, [sw for sw in sweeps if not sw.done])
+            for sw in sweeps:
+                fits[sw.u], njob_out[sw.u] = sw.best, sw.n_jobs
+        for u, (rpj, rout, i) in refit.items():
+            fits[u] = batch.fit_at(rpj, rout, i)
         t2 = _now()
         # ---- labels for every UTR (get_label, :873-881) -------------------------------------------
         kmax_f = max(1, int(Kw.max()), max((f.K for f in fits if f is not None), default=1))
