@@ -224,7 +224,7 @@ def main():
             same = 0
             for u, alpha, beta, ws, bic, nlb in outs:
                 lo = int(plan["spans"][u])
-                grid = bic.reshape(-1, 10)
+                grid = bic.astype(np.float32).reshape(-1, 10)      # the reference's bic_arr is float32
                 tb = np.argmin(grid, axis=1)
                 kb = int(np.argmin(grid[np.arange(len(tb)), tb]))
                 j = kb * 10 + int(tb[kb])

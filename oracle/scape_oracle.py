@@ -333,7 +333,9 @@ class Model:
 
     def em_optim0(self, K):                                       # apa_core.py:846-871
         res = [self.em_algo(self.init_para(K)) for _ in range(10)]
-        return res[int(np.argmin(np.array([p.bic for p in res])))]
+        # bic_arr = np.full(n_trial, np.finfo('f').max) (:849) is a FLOAT32 array: the arg-min over the
+        # restarts sees the BICs rounded to f32 (ties -> first restart)
+        return res[int(np.argmin(np.array([p.bic for p in res], dtype=np.float32)))]
 
     def rm_component(self, para):                                 # apa_core.py:832-844, :708-711
         keep = np.array([i for i in range(para.K) if not para.ws[i] < self.min_ws], dtype=int)
@@ -354,6 +356,34 @@ class Model:
                            _p(a), _p(b), _p(w), _p(lab, _I64))
         return lab
 
+    def marginal_scipy(self, alpha, beta):
+        """ApaModel.loglik_marginal_lxr (apa_core.py:642-651): the numpy/scipy flavour fixed_run uses."""
+        from scipy import stats
+        from scipy.special import logsumexp
+        sel = np.where(np.logical_and(self.all_theta >= alpha - 3 * beta, self.all_theta <= alpha + 3 * beta))[0]
+        logp = stats.norm(loc=alpha, scale=beta).logpdf(self.all_theta[sel])
+        return logsumexp(self.A[:, sel] + logp[None, :], axis=1) - logsumexp(logp)
+
+    def fixed_run(self, pre_para):                                # apa_core.py:883-928 (rm_comp_flag=False)
+        full = np.arange(int(self.min_theta), int(self.L), int(self.theta_step)) + 0.0
+        max_b, min_b = np.max(pre_para.beta_arr), np.min(pre_para.beta_arr)
+        pieces = []
+        for alpha in pre_para.alpha_arr:
+            ind, _ = nearest_on_grid(self.all_theta, np.array([alpha - 3 * max_b, alpha + 3 * max_b]))
+            pieces.append(full[ind[0]:ind[1]])
+        self.all_theta = np.unique(np.concatenate(pieces))
+        self.betas = np.arange(min_b, max_b + self.beta_step, self.beta_step) + 0.0
+        self.A = phase_a(self.x, self.l, self.r, self.pa, self.all_theta, self.s_dis, self.pmf, self.mu_f, self.sigma_f)
+        self.cov = coverage_profile(self.x, self.l, self.cnt, self.L, self.beta_step)
+        self.M = np.zeros((len(self.all_theta), len(self.betas), self.N))
+        for i, a in enumerate(self.all_theta):
+            for j, b in enumerate(self.betas):
+                self.M[i][j] = self.marginal_scipy(a, b)
+        res = self.em_optim0(int(pre_para.K))
+        res.label_arr = self.labels(res)[self.idx]
+        res.title = "Final Result (subsample run)"
+        return res
+
     def run(self, skip_lik=False):                                # apa_core.py:930-981
         if self.n_min_apa > self.n_max_apa:
             raise Exception("n_max_apa has to be greater than n_min_apa!")
@@ -362,19 +392,24 @@ class Model:
         if not skip_lik:
             self.build()
         res = [self.em_optim0(K) for K in range(self.n_max_apa, self.n_min_apa - 1, -1)]
-        best = res[int(np.argmin(np.array([p.bic for p in res])))]
+        # bic_arr of run() is float32 as well (:945): first arg-min of the f32-rounded BICs
+        best = res[int(np.argmin(np.array([p.bic for p in res], dtype=np.float32)))]
         best = self.rm_component(best)
         best.label_arr = self.labels(best)[self.idx]
         best.title = "Final Result"
         return best
 
 
-def subsample_run(x, l, r, pa, re_run_mode=True, **kw):
-    """apa_core.py:984-1035 (normal mode); uses the global numpy RNG like the reference."""
+def subsample_run(x, l, r, pa, re_run_mode=True, pre_para=None, **kw):
+    """apa_core.py:984-1035; uses the global numpy RNG like the reference.  pre_para: fixed_run_mode."""
     utr_len = max(np.max(x) + np.max(l) + 50, kw.get("utr_length", -1))
     kw = dict(kw)
     kw["utr_length"] = utr_len
     kw.setdefault("n_max_apa", 5)
+    if pre_para is not None:                                      # :999-1017
+        kw["utr_length"] = max(utr_len, pre_para.L)
+        model = Model(x, l, r, pa, **kw)
+        return model.fixed_run(pre_para), model
     model = Model(x, l, r, pa, **kw)
     res = model.run()
     while re_run_mode and len(res.alpha_arr) == kw["n_max_apa"]:

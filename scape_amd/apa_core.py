@@ -62,7 +62,7 @@ Parameters.__qualname__ = "Parameters"
 def to_parameters(res):
     """UtrResult -> Parameters with the reference's field set and dtypes."""
     q, f = res.prep, res.fit
-    para = Parameters(title='Final Result',
+    para = Parameters(title='Final Result (subsample run)' if q.fixed_run else 'Final Result',
                       alpha_arr=np.rint(q.theta[f.a_idx]).astype('int'),
                       beta_arr=q.betas[f.b_idx].astype(np.float64),
                       ws=np.array(f.ws, dtype=np.float64), L=int(q.L),
@@ -109,7 +109,13 @@ def infer(pickle_input_file, pickle_output_file, **kwargs):
     print(f"start inferring APA events from input pickle file = {pickle_input_file}. "
           f"Output file = {pickle_output_file}")
     start_t = timer()
-    preps = [prepare_utr(df, gene_info_str=gene, **kwargs) for gene, df in read_input_chunk(pickle_input_file)]
+    pre_para = None
+    if kwargs.get("fixed_run_mode", False):                  # subsample_run (:999-1007)
+        assert kwargs["pre_para_pkl_file"]
+        assert os.path.exists(kwargs["pre_para_pkl_file"])
+        pre_para = next(iter(read_input_chunk(kwargs["pre_para_pkl_file"])))   # first Parameters only (:1002-1003)
+    preps = [prepare_utr(df, gene_info_str=gene, pre_para=pre_para, **kwargs)
+             for gene, df in read_input_chunk(pickle_input_file)]
     engine = Engine(device=kwargs.get("device"))
     results = engine.run(preps, rng_mode=kwargs.get("rng_mode", "reference"), seed=int(kwargs.get("seed", 1)),
                          re_run_mode=bool(kwargs.get("re_run_mode", True)))
@@ -136,8 +142,6 @@ def _infer_pa(pkl_input_file: str, output_dir: str, **kwargs):
     out_pkl_file = os.path.join(output_dir, "pkl_output", filename + ".res.pkl")
     if os.path.exists(out_pkl_file):
         os.remove(out_pkl_file)
-    if kwargs.get("fixed_run_mode", False):
-        raise NotImplementedError("fixed_run_mode / --pre_para_pkl_file is not implemented on the HIP path yet")
     # watch_dog_flag (apa_core.py:140-145) is accepted and ignored: it only logs host CPU/memory
     return infer(pkl_input_file, out_pkl_file, **kwargs)
 

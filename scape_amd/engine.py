@@ -250,9 +250,11 @@ class _Sweep:
             per_k = []
             for i in range(0, len(fits), N_TRIAL):      # em_optim0: first arg-min BIC over trials (:865)
                 grp = fits[i:i + N_TRIAL]
-                per_k.append(grp[int(np.argmin(np.array([f.bic for f in grp])))])
-            self.best = per_k[int(np.argmin(np.array([f.bic for f in per_k])))]     # (:972)
-            if any(self.best.ws[i] < q.p["min_ws"] for i in range(self.best.K)):
+                # bic_arr is np.full(n, np.finfo('f').max): a float32 array (:849, :945), so both
+                # arg-mins compare BICs rounded to f32 (ties -> first)
+                per_k.append(grp[int(np.argmin(np.array([f.bic for f in grp], dtype=np.float32)))])
+            self.best = per_k[int(np.argmin(np.array([f.bic for f in per_k], dtype=np.float32)))]     # (:972)
+            if not q.fixed_run and any(self.best.ws[i] < q.p["min_ws"] for i in range(self.best.K)):
                 self.stage = "prune"
                 return
         elif self.stage == "prune":
@@ -263,14 +265,14 @@ class _Sweep:
         """Entry for the vectorised selection: the sweep's BIC winner is already known."""
         self.best = best
         self.n_jobs += n_jobs
-        if any(best.ws[i] < self.prep.p["min_ws"] for i in range(best.K)):
+        if not self.prep.fixed_run and any(best.ws[i] < self.prep.p["min_ws"] for i in range(best.K)):
             self.stage = "prune"
             return
         self._after_fit()
 
     def _after_fit(self):
-        # re-run rule of subsample_run (:1023-1030)
-        if self.re_run and self.best.K == self.n_max:
+        # re-run rule of subsample_run (:1023-1030); fixed_run returns before it (:1009-1017)
+        if self.re_run and not self.prep.fixed_run and self.best.K == self.n_max:
             self.n_min = self.n_max
             self.n_max = self.n_max + 2
             self.stage = "sweep"
@@ -326,7 +328,7 @@ class Engine:
         for wave in self.waves(preps):
             wp = [preps[i] for i in wave]
             batch = HipBatch(self.ctx, wp)
-            if rng_mode == "reference" or keep_trace:
+            if rng_mode == "reference" or keep_trace or any(q.fixed_run for q in wp):
                 batch.build()
                 sweeps = []
                 for u, gi in enumerate(wave):
@@ -396,9 +398,11 @@ class Engine:
         U = len(preps)
         # ---- em_optim0 (:865) + run (:972): first arg-min BIC over restarts, then over K (desc) ----
         njobs = np.diff(spans)
+        with np.errstate(over="ignore"):
+            bic32 = bic.astype(np.float32)      # the reference's bic_arr is float32 (:849, :945)
         if np.all(njobs == njobs[0]):
             nk = int(njobs[0]) // N_TRIAL
-            grid = bic.reshape(U, nk, N_TRIAL)
+            grid = bic32.reshape(U, nk, N_TRIAL)
             tb = np.argmin(grid, axis=2)
             kb = np.argmin(np.take_along_axis(grid, tb[:, :, None], axis=2)[:, :, 0], axis=1)
             win = spans[:-1] + kb * N_TRIAL + tb[np.arange(U), kb]
@@ -406,7 +410,7 @@ class Engine:
             win = np.zeros(U, dtype=np.int64)
             for u in range(U):
                 lo, hi = int(spans[u]), int(spans[u + 1])
-                g = bic[lo:hi].reshape(-1, N_TRIAL)
+                g = bic32[lo:hi].reshape(-1, N_TRIAL)
                 tbu = np.argmin(g, axis=1)
                 kbu = int(np.argmin(g[np.arange(len(tbu)), tbu]))
                 win[u] = lo + kbu * N_TRIAL + int(tbu[kbu])

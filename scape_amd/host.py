@@ -113,6 +113,7 @@ class UtrPrep:
     unif_ll: float
     peaks: np.ndarray = None
     peak_w: np.ndarray = None
+    fixed_run: bool = False      # --pre_para_pkl_file mode (apa_core.py:883-928)
 
     @property
     def N(self):
@@ -123,11 +124,15 @@ class UtrPrep:
         return len(self.theta)
 
 
-def prepare_utr(df, gene_info_str="None", **kwargs):
-    """subsample_run head (:994-997) + ApaModel.__init__ (:333-437) + run() grids (:940-951)."""
+def prepare_utr(df, gene_info_str="None", pre_para=None, **kwargs):
+    """subsample_run head (:994-997) + ApaModel.__init__ (:333-437) + run() grids (:940-951).
+    With `pre_para` (fixed_run_mode, :999-1009 and :883-897): theta grid restricted to +-3 max(beta)
+    around the given alphas, beta grid spanning the given betas, K fixed to pre_para.K."""
     p = model_params(kwargs)
     x_raw, l_raw = np.asarray(df["x"]), np.asarray(df["l"])
     utr_len = max(int(x_raw.max()) + int(l_raw.max()) + 50, kwargs.get("utr_length", -1) or -1)
+    if pre_para is not None:
+        utr_len = max(utr_len, int(pre_para.L))
     bx, bl, br, bpa, cnt, idx = bin_reads(df["x"], df["l"], df["r"], df["pa"])
     L = utr_len if utr_len > 2000 else 2000
     if not np.all((bx >= 0) & (bx < utr_len)):
@@ -144,11 +149,23 @@ def prepare_utr(df, gene_info_str="None", **kwargs):
     min_theta = int(min(bl)) + 0.0
     theta = np.arange(int(min_theta), int(L), int(p["theta_step"])) + 0.0
     betas = np.arange(p["beta_step"], p["max_beta"], p["beta_step"]) + 0.0
+    if pre_para is not None:                                                    # fixed_run (:888-896)
+        pb = np.asarray(pre_para.beta_arr, dtype=np.float64)
+        max_b, min_b = float(np.max(pb)), float(np.min(pb))
+        pieces = []
+        for alpha in np.asarray(pre_para.alpha_arr):
+            i0, i1 = snap_to_grid(theta, np.array([alpha - 3 * max_b, alpha + 3 * max_b]))
+            pieces.append(theta[i0:i1])
+        theta = np.unique(np.concatenate(pieces))
+        betas = np.arange(min_b, max_b + p["beta_step"], p["beta_step"]) + 0.0
+        p = dict(p, n_max_apa=int(pre_para.K), n_min_apa=int(pre_para.K))
+        if len(theta) == 0:
+            raise ValueError("fixed_run: the pre-specified pA sites leave no theta grid point")
     unif_ll = float(np.log((1 / L) * (1 / L) * (1 / p["max_LA"])))
     prep = UtrPrep(gene_info_str=gene_info_str, p=p, x=bx, l=bl, r=br, pa=bpa, cnt=cnt, idx=idx,
                    cb_id=np.array(df["cb_id"]), read_id=np.array(df["read_id"]), L=int(L),
                    min_theta=min_theta, theta=theta, betas=betas, s_dis=s_dis.astype(np.float64),
-                   pmf_s=pmf, unif_ll=unif_ll)
+                   pmf_s=pmf, unif_ll=unif_ll, fixed_run=pre_para is not None)
     # coverage peaks used by sample_alpha (:782-794) - data only, no RNG
     xs, ys = coverage_profile(bx, bl, cnt, L, p["beta_step"])
     pk, _ = find_peaks(ys, distance=p["min_pa_gap"])

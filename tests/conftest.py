@@ -31,6 +31,15 @@ def trace_params(f):
     return p
 
 
+def trace_pre_para(f):
+    """pre-specified Parameters of a fixed_run_mode trace (None for ordinary traces)."""
+    if "pre_alpha_arr" not in f.files:
+        return None
+    from types import SimpleNamespace
+    return SimpleNamespace(alpha_arr=f["pre_alpha_arr"], beta_arr=f["pre_beta_arr"], ws=f["pre_ws"],
+                           L=int(f["pre_L"]), K=len(f["pre_alpha_arr"]))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import scape_oracle
@@ -44,5 +53,5 @@ def hip_ctx():
     return _lib.default_context(0)
 
 
-TRACES = ["synA", "synB", "chr17", "chr19", "toy"]
+TRACES = ["synA", "synB", "synF", "chr17", "chr19", "toy"]
 FIXTURES = ["chr17", "chr19", "toy"]

@@ -201,7 +201,7 @@ def _pack_calls(calls, kmax):
     return out
 
 
-def run_reference_file(name, utrs, params, seed=1, tensor_stride=7, keep_full_tensor=False):
+def run_reference_file(name, utrs, params, seed=1, tensor_stride=7, keep_full_tensor=False, pre_para=None):
     """Mimic _infer_pa/infer (apa_core.py:107-147, :1104-1137) on a list of (gene, DataFrame)."""
     ac, _tc = load_reference()
     rec = Recorder(ac)
@@ -209,6 +209,9 @@ def run_reference_file(name, utrs, params, seed=1, tensor_stride=7, keep_full_te
     for k, v in params.items():
         if v is not None:
             d["param_" + k] = np.array(v)
+    if pre_para is not None:
+        for k, v in pre_para.items():
+            d["pre_" + k] = np.asarray(v)
     try:
         np.random.seed(seed)
         for i, (gene, df) in enumerate(utrs):
@@ -220,6 +223,16 @@ def run_reference_file(name, utrs, params, seed=1, tensor_stride=7, keep_full_te
             kw = dict(params)
             kw["data"] = df
             kw["gene_info_str"] = gene
+            if pre_para is not None:      # --pre_para_pkl_file mode: the reference reads OUR temp pickle
+                import pickle
+                import tempfile
+                tmp = tempfile.NamedTemporaryFile(suffix=".pkl", delete=False, dir="/tmp")
+                pickle.dump(ac.Parameters(title="pre", alpha_arr=np.asarray(pre_para["alpha_arr"]),
+                                          beta_arr=np.asarray(pre_para["beta_arr"], dtype=np.float64),
+                                          ws=np.asarray(pre_para["ws"]), L=int(pre_para["L"])), tmp)
+                tmp.close()
+                kw["fixed_run_mode"] = True
+                kw["pre_para_pkl_file"] = tmp.name
             with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
                 res, model = ac.subsample_run(return_model=True, **kw)
             dt = time.time() - t0
@@ -330,6 +343,19 @@ def write_synth():
     run_reference_file("synB", utrs, p, seed=7, keep_full_tensor=True)
 
 
+def write_fixed():
+    """fixed_run_mode (apa_core.py:883-928, :999-1017): two synthetic UTRs, K and grids from a given result."""
+    rng = np.random.default_rng(77)
+    utrs = [
+        ("synF:g1:1:1-2000:+", synth_utr(rng, 240, [650, 1500], [20, 30], [0.5, 0.5], 2000, pa_rate=0.05)),
+        ("synF:g2:1:1-2000:+", synth_utr(rng, 200, [700, 1450], [25, 25], [0.4, 0.6], 2000, pa_rate=0.0, r_rate=0.1)),
+    ]
+    p = dict(DEFAULT_PARAMS)
+    p["n_max_apa"] = 3
+    pre = dict(alpha_arr=np.array([660, 1490]), beta_arr=np.array([15.0, 35.0]), ws=np.array([0.5, 0.45, 0.05]), L=2100)
+    run_reference_file("synF", utrs, p, seed=3, keep_full_tensor=True, pre_para=pre)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     names = sys.argv[2:] or list(FIXTURE_FILES)
@@ -337,5 +363,7 @@ if __name__ == "__main__":
         write_fixtures()
     if what in ("synth", "all"):
         write_synth()
+    if what in ("fixed", "all"):
+        write_fixed()
     if what in ("traces", "all"):
         write_traces(names)

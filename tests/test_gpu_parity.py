@@ -12,7 +12,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import FIXTURES, TRACES, load_npz, trace_params, utr_df
+from conftest import FIXTURES, TRACES, load_npz, trace_params, trace_pre_para, utr_df
 
 pytestmark = pytest.mark.gpu
 SENT = float(np.finfo("f").min)
@@ -107,7 +107,7 @@ def _batch_for_trace(hip_ctx, name):
     preps = []
     for i in range(int(f["n_utr"])):
         gene, df = utr_df(f, i)
-        preps.append(prepare_utr(df, gene_info_str=gene, **p))
+        preps.append(prepare_utr(df, gene_info_str=gene, pre_para=trace_pre_para(f), **p))
     batch = HipBatch(hip_ctx, preps)
     batch.build()
     return f, p, preps, batch
@@ -176,7 +176,8 @@ def test_full_pipeline_reference_stream(name):
     from scape_amd.host import prepare_utr
     f = load_npz(f"trace_{name}.npz")
     p = trace_params(f)
-    preps = [prepare_utr(utr_df(f, i)[1], gene_info_str=utr_df(f, i)[0], **p) for i in range(int(f["n_utr"]))]
+    preps = [prepare_utr(utr_df(f, i)[1], gene_info_str=utr_df(f, i)[0], pre_para=trace_pre_para(f), **p)
+             for i in range(int(f["n_utr"]))]
     eng = Engine(device=0)
     res = eng.run(preps, rng_mode="reference", seed=int(f["seed"]), re_run_mode=bool(p["re_run_mode"]), keep_trace=True)
     for i, r in enumerate(res):
@@ -189,7 +190,7 @@ def test_full_pipeline_reference_stream(name):
         assert para.bic == pytest.approx(float(f[f"u{i}_res_bic"]), rel=1e-10)
         assert np.array_equal(para.label_arr, f[f"u{i}_res_label_arr"])
         assert np.allclose(para.lb_arr, f[f"u{i}_res_lb_arr"], rtol=1e-10)
-        assert para.L == int(f[f"u{i}_L"]) and para.title == "Final Result"
+        assert para.L == int(f[f"u{i}_L"]) and para.title == str(f[f"u{i}_res_title"])
         assert np.array_equal(para.cb_id_arr, f[f"u{i}_cb_id"]) and np.array_equal(para.readID_arr, f[f"u{i}_read_id"])
 
 
@@ -374,3 +375,49 @@ def test_properties_headline_shape():
     for a, b in zip(r1, r3):
         assert a.fit.K == b.fit.K and np.array_equal(a.fit.a_idx, b.fit.a_idx) and np.array_equal(a.fit.b_idx, b.fit.b_idx)
         assert np.array_equal(a.fit.ws, b.fit.ws) and a.fit.bic == b.fit.bic and np.array_equal(a.labels_bin, b.labels_bin)
+
+
+def test_cli_fixed_run_mode_vs_oracle(tmp_path, oracle):
+    """--pre_para_pkl_file (reference apa_core.py:94-99, :999-1017, :883-928): K and grids come from the first
+    Parameters of a result file; same RNG stream as the reference -> compare with the oracle's fixed_run."""
+    from types import SimpleNamespace
+    from click.testing import CliRunner
+    from scape.apa_core import Parameters
+    from scape.cli import cli
+    from scape_amd.synth import synth_chunk
+    chunk = synth_chunk(3, 400, k_cap=3, base_seed=500, pa_rate=0.03)
+    out = tmp_path / "out"
+    (out / "pkl_input").mkdir(parents=True)
+    inp = out / "pkl_input" / "fx.100.1.1.input.pkl"
+    with open(inp, "wb") as fh:
+        for g, df in chunk:
+            pickle.dump((g, df), fh)
+    (out / "parameters.toml").write_text("n_max_apa = 4\nre_run_mode = true\n")
+    pre = Parameters(title="Final Result", alpha_arr=np.array([700, 1600]), beta_arr=np.array([20.0, 40.0]),
+                     ws=np.array([0.5, 0.45, 0.05]), L=2500)
+    pre_file = tmp_path / "pre.res.pkl"
+    with open(pre_file, "wb") as fh:
+        pickle.dump(pre, fh)
+        pickle.dump(pre, fh)                       # only the first object is used (apa_core.py:1002-1003)
+    r = CliRunner().invoke(cli, ["infer_pa", "--pkl_input_file", str(inp), "--output_dir", str(out),
+                                 "--pre_para_pkl_file", str(pre_file)])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    toml = (out / "parameters.toml").read_text()
+    assert "fixed_run_mode = true" in toml and "pre_para_pkl_file" in toml      # rewritten like tomli_w.dump (:98-99)
+    got = []
+    with open(out / "pkl_output" / "fx.100.1.1.res.pkl", "rb") as fh:
+        while True:
+            try:
+                got.append(pickle.load(fh))
+            except EOFError:
+                break
+    np.random.seed(1)
+    pre_ns = SimpleNamespace(alpha_arr=pre.alpha_arr, beta_arr=pre.beta_arr, ws=pre.ws, L=2500, K=2)
+    for (g, df), para in zip(chunk, got):
+        want, _m = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values,
+                                        pre_para=pre_ns, n_max_apa=4)
+        assert para.title == "Final Result (subsample run)" and para.K == 2 and para.L == max(2500, want and para.L)
+        assert np.array_equal(para.alpha_arr, want.alpha_arr) and np.array_equal(para.beta_arr, want.beta_arr)
+        assert np.allclose(para.ws, want.ws, rtol=1e-9, atol=1e-13)
+        assert para.bic == pytest.approx(want.bic, rel=1e-10)
+        assert np.array_equal(para.label_arr, want.label_arr)

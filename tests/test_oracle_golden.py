@@ -12,7 +12,7 @@ import math
 import numpy as np
 import pytest
 
-from conftest import FIXTURES, TRACES, load_npz, trace_params
+from conftest import FIXTURES, TRACES, load_npz, trace_params, trace_pre_para
 
 SENT = float(np.finfo("f").min)
 
@@ -93,7 +93,7 @@ def _run_oracle_on_trace(oracle, name):
         assert np.array_equal(st[1], f[f"u{i}_rng_keys"]) and st[2] == int(f[f"u{i}_rng_pos"]), \
             f"{name} u{i}: RNG stream position differs from the reference before this UTR"
         res, model = oracle.subsample_run(f[f"u{i}_x"], f[f"u{i}_l"], f[f"u{i}_r"], f[f"u{i}_pa"],
-                                          re_run_mode=re_run, **p)
+                                          re_run_mode=re_run, pre_para=trace_pre_para(f), **p)
         out.append((res, model))
     return f, out
 
@@ -147,6 +147,7 @@ def test_oracle_reproduces_reference_trace(oracle, name):
         assert np.allclose(res.ws, f[f"u{i}_res_ws"], rtol=1e-10, atol=1e-14), tag
         assert res.bic == pytest.approx(float(f[f"u{i}_res_bic"]), rel=1e-11), tag
         assert np.array_equal(res.label_arr, f[f"u{i}_res_label_arr"]), tag
+        assert res.title == str(f[f"u{i}_res_title"]), tag
 
 
 # ---------------------------------------------------------------- (3) committed example outputs
