@@ -1,7 +1,7 @@
 """click group exposing ``infer_pa`` (reference cli.py:7-31 registers six commands)."""
 import click
 
-from scape_amd.apa_core import infer_pa
+from scape_amd.apa_core import infer_pa, infer_pa_all
 
 
 @click.group()
@@ -17,3 +17,4 @@ def display_paper_info():
 
 
 cli.add_command(infer_pa)
+cli.add_command(infer_pa_all)

@@ -146,6 +146,88 @@ def _infer_pa(pkl_input_file: str, output_dir: str, **kwargs):
     return infer(pkl_input_file, out_pkl_file, **kwargs)
 
 
+def _load_preps(pkl_input_file, kwargs):
+    pre_para = None
+    if kwargs.get("fixed_run_mode", False):
+        pre_para = next(iter(read_input_chunk(kwargs["pre_para_pkl_file"])))
+    return [prepare_utr(df, gene_info_str=gene, pre_para=pre_para, **kwargs)
+            for gene, df in read_input_chunk(pkl_input_file)]
+
+
+def infer_files(files, output_dir, device=None, files_in_flight=32, **kwargs):
+    """Several chunk files on one GPU.  Each file keeps the reference's own random stream
+    (np.random.seed(1) per file, apa_core.py:125) and UTR order, so every <stem>.res.pkl equals what
+    `scape infer_pa` writes for that file; the files only share the GPU launches."""
+    from .engine import Engine
+    os.makedirs(os.path.join(output_dir, "pkl_output"), exist_ok=True)
+    engine = Engine(device=device)
+    written = []
+    for i in range(0, len(files), files_in_flight):
+        group = files[i:i + files_in_flight]
+        streams = [(_load_preps(f, kwargs), int(kwargs.get("seed", 1))) for f in group]
+        per_file = engine.run_streams(streams, re_run_mode=bool(kwargs.get("re_run_mode", True)))
+        for f, results in zip(group, per_file):
+            out = os.path.join(output_dir, "pkl_output", os.path.basename(f)[:-10] + ".res.pkl")
+            with open(out, "wb") as fh:
+                for r in results:
+                    pickle.dump(to_parameters(r), fh)
+            written.append(out)
+    return written
+
+
+def _infer_files_worker(rank, files, output_dir, kwargs):
+    os.environ["LOCAL_RANK"] = str(rank)
+    infer_files(files, output_dir, device=rank, **kwargs)
+
+
+def infer_all(output_dir, gpus=1, **kwargs):
+    """Every complete chunk of <output_dir>/pkl_input on `gpus` GPUs of this node: chunk files are sharded
+    over one worker process per GPU (largest-first by file size), no communication between workers
+    (merge_pa expects one .res.pkl per .input.pkl, reference junction_handler.py:59-64)."""
+    import glob
+    import multiprocessing as mp
+
+    from .dist import lpt_partition
+    files = sorted(f for f in glob.glob(os.path.join(output_dir, "pkl_input", "*.input.pkl"))
+                   if ".tmp." not in os.path.basename(f))
+    if not files:
+        raise Exception("no *.input.pkl under " + os.path.join(output_dir, "pkl_input"))
+    shards = lpt_partition([os.path.getsize(f) for f in files], gpus)
+    if gpus == 1:
+        infer_files(files, output_dir, device=kwargs.pop("device", None), **kwargs)
+        return files
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_infer_files_worker, args=(r, [files[i] for i in shards[r]], output_dir, kwargs))
+             for r in range(gpus) if shards[r]]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join()
+    bad = [p.exitcode for p in procs if p.exitcode != 0]
+    if bad:
+        raise Exception(f"infer_pa_all: {len(bad)} worker(s) failed")
+    return files
+
+
+@click.command(name="infer_pa_all")
+@click.option('--output_dir', type=str, help='output directory of prepare_input (holds pkl_input/ and parameters.toml)',
+              required=True)
+@click.option('--toml_para_file', type=str, default=None, required=False)
+@click.option('--gpus', type=int, default=1, help='number of GPUs of this node to shard the chunk files over')
+def infer_pa_all(output_dir: str, toml_para_file: str = None, gpus: int = 1):
+    """infer_pa for every chunk under <output_dir>/pkl_input (not in the reference CLI: its tutorial
+    loops `scape infer_pa` over the files in a shell, SCAPE-example-with-DE.ipynb cell 8)."""
+    assert Path(output_dir).exists()
+    para_dict = {"n_max_apa": 5}
+    if toml_para_file is None:
+        toml_para_file = Path(output_dir) / "parameters.toml"
+    assert os.path.exists(toml_para_file)
+    with open(toml_para_file, "rb") as fh:
+        para_dict.update(_toml.load(fh))
+    para_dict.pop("output_dir", None)
+    infer_all(output_dir, gpus=gpus, **para_dict)
+
+
 @click.command(name="infer_pa")
 @click.option('--pkl_input_file', type=str, help='input pickle file (result of prepare_input)', required=True)
 @click.option('--output_dir', type=str, help='output directory', required=True)

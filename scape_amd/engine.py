@@ -348,6 +348,77 @@ class Engine:
                 results[gi].fit, results[gi].labels_bin, results[gi].n_jobs = fit, lab, nj
         return results
 
+    # ---- several reference-RNG streams at once (one stream = one chunk file) --------------------------
+    def run_streams(self, streams, re_run_mode=True):
+        """streams: list of (preps, seed).  Every stream keeps the reference's serial RandomState(seed)
+        semantics (its UTRs are processed one after another, draws in the reference's order), but the
+        current UTRs of ALL streams share each EM launch - chunk files are independent random streams
+        (np.random.seed(1) per file, apa_core.py:125), so results equal running the files one by one."""
+        flat, owner = [], []
+        for si, (preps, _seed) in enumerate(streams):
+            for q in preps:
+                flat.append(q)
+                owner.append(si)
+        results = [UtrResult(prep=q) for q in flat]
+        samplers = [Sampler(np.random.RandomState(seed)) for _p, seed in streams]
+        # streams advance monotonically, so waves are cut over the flat list in round-robin stream order
+        order = []
+        cursors = [0] * len(streams)
+        starts = np.cumsum([0] + [len(p) for p, _ in streams])
+        while True:
+            took = False
+            for si, (preps, _seed) in enumerate(streams):
+                if cursors[si] < len(preps):
+                    order.append(int(starts[si]) + cursors[si])
+                    cursors[si] += 1
+                    took = True
+            if not took:
+                break
+        budget = self._budget()
+        pos = 0
+        while pos < len(order):
+            wave, used = [], 0
+            while pos < len(order) and len(wave) < 65535:
+                b = self.utr_bytes(flat[order[pos]])
+                if wave and used + b > budget:
+                    break
+                if b > budget:
+                    raise _lib.ScapeHipError("a UTR's marginal tensor exceeds device memory")
+                wave.append(order[pos])
+                used += b
+                pos += 1
+            wave.sort()                              # keep each stream's UTRs in file order inside the wave
+            batch = HipBatch(self.ctx, [flat[g] for g in wave])
+            batch.build()
+            queues = {}
+            for u, g in enumerate(wave):
+                queues.setdefault(owner[g], []).append(_Sweep(u, flat[g], samplers[owner[g]], re_run_mode))
+            done_sweeps = []
+            while queues:
+                heads = [q[0] for q in queues.values()]
+                jobs, spans = [], []
+                for sw in heads:
+                    js = sw.make_jobs()
+                    spans.append((len(jobs), len(jobs) + len(js)))
+                    jobs.extend(js)
+                fits = batch.em(jobs)
+                for sw, (a, b) in zip(heads, spans):
+                    sw.absorb(fits[a:b])
+                for si in list(queues):
+                    if queues[si][0].done:
+                        done_sweeps.append(queues[si].pop(0))
+                        if not queues[si]:
+                            del queues[si]
+            labs = batch.labels([(sw.u, sw.best) for sw in done_sweeps])
+            for sw in done_sweeps:
+                g = wave[sw.u]
+                results[g].fit, results[g].labels_bin, results[g].n_jobs = sw.best, labs[sw.u], sw.n_jobs
+        out, k = [], 0
+        for preps, _seed in streams:
+            out.append(results[k:k + len(preps)])
+            k += len(preps)
+        return out
+
     # ---- fully batched path (per-UTR RNG): pre-drawn job tables + vectorised selection -------------
     @staticmethod
     def plan(preps, seeds):

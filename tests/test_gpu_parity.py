@@ -421,3 +421,45 @@ def test_cli_fixed_run_mode_vs_oracle(tmp_path, oracle):
         assert np.allclose(para.ws, want.ws, rtol=1e-9, atol=1e-13)
         assert para.bic == pytest.approx(want.bic, rel=1e-10)
         assert np.array_equal(para.label_arr, want.label_arr)
+
+
+def test_infer_pa_all_equals_per_file_runs(tmp_path):
+    """The chunk-directory driver keeps each file's own reference RNG stream while sharing GPU launches:
+    every <stem>.res.pkl equals the one `scape infer_pa` writes for that file alone."""
+    from click.testing import CliRunner
+    from scape.cli import cli
+    from scape_amd.synth import synth_chunk
+    out = tmp_path / "out"
+    (out / "pkl_input").mkdir(parents=True)
+    (out / "parameters.toml").write_text("n_max_apa = 3\nre_run_mode = true\n")
+    files = []
+    for fi, n in enumerate((3, 1, 4)):
+        f = out / "pkl_input" / f"s{fi}.100.3.{fi + 1}.input.pkl"
+        with open(f, "wb") as fh:
+            for g, df in synth_chunk(n, 250 + 50 * fi, k_cap=3, base_seed=900 + 10 * fi, pa_rate=0.04):
+                pickle.dump((g, df), fh)
+        files.append(f)
+    (out / "pkl_input" / "s9.tmp.100.3.9.input.pkl").write_bytes(b"")        # incomplete chunk: skipped
+    r = CliRunner().invoke(cli, ["infer_pa_all", "--output_dir", str(out)])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+
+    def load(p):
+        res = []
+        with open(p, "rb") as fh:
+            while True:
+                try:
+                    res.append(pickle.load(fh))
+                except EOFError:
+                    return res
+    together = {f.name: load(out / "pkl_output" / (f.name[:-10] + ".res.pkl")) for f in files}
+    assert not (out / "pkl_output" / "s9.tmp.100.3.9.res.pkl").exists()
+    for f in files:
+        r = CliRunner().invoke(cli, ["infer_pa", "--pkl_input_file", str(f), "--output_dir", str(out)])
+        assert r.exit_code == 0, r.output + repr(r.exception)
+        alone = load(out / "pkl_output" / (f.name[:-10] + ".res.pkl"))
+        assert len(alone) == len(together[f.name])
+        for a, b in zip(alone, together[f.name]):
+            assert a.gene_info_str == b.gene_info_str and a.K == b.K
+            assert np.array_equal(a.alpha_arr, b.alpha_arr) and np.array_equal(a.beta_arr, b.beta_arr)
+            assert np.array_equal(a.ws, b.ws) and a.bic == b.bic and np.array_equal(a.label_arr, b.label_arr)
+            assert np.array_equal(a.lb_arr, b.lb_arr)
