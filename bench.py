@@ -104,16 +104,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    from scape_amd import _lib as _sl
+    dev = local_rank % max(1, _sl.device_count())      # one rank per GPU (modulo only matters on a 1-GPU test box)
     if world > 1:
+        # The data path has no collective (UTR shards are independent), so the process group is only used for
+        # the barrier and the max-over-ranks time: gloo on the host.  torch.cuda is deliberately never
+        # initialised - torch bundles its own HIP runtime and this library links the system one.
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            tdev = torch.device("cuda", local_rank)
-        except Exception:
-            dist.init_process_group(backend="gloo")
-            tdev = torch.device("cpu")
+        dist.init_process_group(backend="gloo")
+        tdev = torch.device("cpu")
 
     from scape_amd.engine import Engine, HipBatch
     from scape_amd.host import prepare_utr
@@ -126,7 +126,7 @@ def main():
     for i in range(U):
         gene, df, _truth = synth_utr(rank * U + i, args.reads, k_cap=args.kcap, base_seed=args.base_seed)
         preps.append(prepare_utr(df, gene_info_str=gene, **kw))
-    eng = Engine(device=local_rank)
+    eng = Engine(device=dev)
     plan = eng.plan(preps, [(args.base_seed + rank * U + i) % 2 ** 32 for i in range(U)])
     t_prep = time.perf_counter() - t_prep
     t_h2d = time.perf_counter()
@@ -134,11 +134,9 @@ def main():
     t_h2d = time.perf_counter() - t_h2d
 
     def sync_all():
+        # every C-ABI call returns with its stream synchronised, so the device is idle here
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
 
     def step():
         return eng.process(batch, preps, plan, re_run_mode=False)
