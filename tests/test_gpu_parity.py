@@ -463,3 +463,33 @@ def test_infer_pa_all_equals_per_file_runs(tmp_path):
             assert np.array_equal(a.alpha_arr, b.alpha_arr) and np.array_equal(a.beta_arr, b.beta_arr)
             assert np.array_equal(a.ws, b.ws) and a.bic == b.bic and np.array_equal(a.label_arr, b.label_arr)
             assert np.array_equal(a.lb_arr, b.lb_arr)
+
+
+@pytest.mark.parametrize("reads,kcap,n", [(10000, 10, 2), (5000, 12, 2)])
+def test_deep_pileup_shapes_vs_oracle(oracle, reads, kcap, n):
+    """BASELINE configs #4 (10k reads, K<=10) and #5 (5k reads, K=1..12) shapes, two UTRs each, every job
+    checked against the oracle through the per-UTR RNG mode."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_chunk
+    chunk = synth_chunk(n, reads, k_cap=min(kcap, 5), base_seed=31337 + reads)
+    kw = dict(n_max_apa=kcap, n_min_apa=1)
+    preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in chunk]
+    eng = Engine(device=0)
+    res = eng.run(preps, rng_mode="per_utr", seed=5, re_run_mode=False, keep_trace=True)
+    for i, ((g, df), r) in enumerate(zip(chunk, res)):
+        np.random.seed(5 + i)
+        want, model = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values,
+                                           re_run_mode=False, **kw)
+        assert len(eng.traces[i]) == len(model.calls)
+        q = r.prep
+        same = 0
+        for ft, rc in zip(eng.traces[i], model.calls):
+            same += (np.array_equal(q.theta[ft.a_idx], rc["a1"]) and np.array_equal(q.betas[ft.b_idx], rc["b1"])
+                     and len(ft.lb) == len(rc["lb"]) and np.allclose(ft.ws, rc["w1"], rtol=1e-6, atol=1e-10))
+        assert same == len(model.calls), f"{g}: {same}/{len(model.calls)} em_algo calls identical"
+        para = to_parameters(r)
+        assert para.K == want.K and np.array_equal(para.alpha_arr, want.alpha_arr)
+        assert np.array_equal(para.beta_arr, want.beta_arr) and np.array_equal(para.label_arr, want.label_arr)
+        assert np.allclose(para.ws, want.ws, rtol=1e-4, atol=1e-9)
