@@ -245,10 +245,15 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                                                  const double *__restrict__ AT,
                                                  const double *__restrict__ V,
                                                  double *__restrict__ M, int Wmax, int all_log,
-                                                 int *__restrict__ err_flag) {
+                                                 int *__restrict__ err_flag, int n_utr, int T_max) {
     extern __shared__ double sm[];
-    const UtrDesc d = descs[blockIdx.y];
-    const int i = blockIdx.x;
+    // blocks b and b+8 share an XCD: all grid points of a UTR go to one XCD so its V rows (each is
+    // read by ~43 neighbouring alphas) are fetched into one L2 only.  Placement only affects speed.
+    const int id = blockIdx.x, slot = id >> 3;
+    const int uu = (slot / T_max) * 8 + (id & 7);
+    if (uu >= n_utr) return;
+    const UtrDesc d = descs[uu];
+    const int i = slot % T_max;
     if (i >= d.T) return;
     const int B = P.B;
     const int tid = threadIdx.x;
@@ -822,13 +827,13 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
     HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
     const size_t lds = ((size_t)2 * prm.B * Wmax + prm.B) * sizeof(double) + (size_t)2 * prm.B * sizeof(int);
     if (lds > 150 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
-    dim3 grid(T_max, n_utr);
+    dim3 grid((unsigned)(((n_utr + 7) / 8) * 8 * T_max));
     if (prm.B <= 16)
         hipLaunchKernelGGL(k_phase_b<16>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>());
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
     else
         hipLaunchKernelGGL(k_phase_b<1>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>());
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -909,19 +914,20 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
     }
     const bool fine = getenv("SCAPE_HIP_ROUND_TIMING") != nullptr;
+    const int dbg_e = getenv("SCAPE_HIP_DBG_E") ? atoi(getenv("SCAPE_HIP_DBG_E")) : 0;   // timing experiments only
     bool any_m = false;   // fixed-inference jobs (mstep_fixed) have no grid arg-max
     for (size_t j = 0; j < nj && !any_m; ++j) any_m = job_fixed[j] == 0;
     unsigned long long executed_prev = 0;
     for (int r = 0; r <= nround; ++r) {
         if (fine && ev_begin(c, 4)) return 1;
 #define LAUNCH_E(CM)                                                                                           \
-    hipLaunchKernelGGL(k2_estep<CM>, dim3(n_jobs), dim3(64), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm,    \
+    hipLaunchKernelGGL(k2_estep<CM>, dim3((unsigned)(((n_jobs + 7) / 8) * 8)), dim3(64), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm,    \
                        c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),               \
                        c->j_K.as<int32_t>(), c->j_fixed.as<int32_t>(), c->j_a.as<int32_t>(),                   \
                        c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(), S,                  \
                        c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                    \
                        c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                    \
-                       c->d_counters.as<unsigned long long>(), r)
+                       c->d_counters.as<unsigned long long>(), r, n_jobs, dbg_e)
         if (kmax + 1 <= 4) LAUNCH_E(4);
         else if (kmax + 1 <= 8) LAUNCH_E(8);
         else if (kmax + 1 <= 12) LAUNCH_E(12);
