@@ -735,7 +735,7 @@ struct EventPair {
 
 struct scape_hip_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
     char name[256] = {0};
     DevParams prm;
     bool loaded = false, built = false;
@@ -917,37 +917,65 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     const int dbg_e = getenv("SCAPE_HIP_DBG_E") ? atoi(getenv("SCAPE_HIP_DBG_E")) : 0;   // timing experiments only
     bool any_m = false;   // fixed-inference jobs (mstep_fixed) have no grid arg-max
     for (size_t j = 0; j < nj && !any_m; ++j) any_m = job_fixed[j] == 0;
+    // Two halves of the UTRs advance on two streams: the E-step is f64-VALU work, the M-step an HBM stream,
+    // so one half's E-step overlaps the other half's M-step.  (Per-kernel event timing and the debug
+    // counters use a single stream.)
+    // Measured (512 UTRs x 2k reads): no gain - the M-step needs 256 VGPRs x 2 waves/SIMD to stream at full
+    // rate, which leaves no room for E-step waves on the same SIMD - so it is off unless requested.
+    const bool split = any_m && !fine && !debug && c->n_utr >= 16 && n_jobs >= 2048 && getenv("SCAPE_HIP_TWO_STREAMS");
+    const int n_grp = split ? 2 : 1;
+    int g_u0[3] = {0, split ? c->n_utr / 2 : c->n_utr, c->n_utr};
+    hipStream_t g_stream[2] = {c->stream, c->stream2};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (split) {
+        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev_fork, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, ev_fork, 0));
+    }
     unsigned long long executed_prev = 0;
-    for (int r = 0; r <= nround; ++r) {
-        if (fine && ev_begin(c, 4)) return 1;
+    int rc = 0;
+    for (int r = 0; r <= nround && !rc; ++r) {
+        for (int g = 0; g < n_grp && !rc; ++g) {
+            const int u0 = g_u0[g], u1 = g_u0[g + 1];
+            const int64_t j0 = ujoff[u0], j1 = ujoff[u1];
+            const int ngj = (int)(j1 - j0);
+            if (ngj == 0) continue;
+            hipStream_t st = g_stream[g];
+            const int32_t *jl = c->e_ujlist.as<int32_t>() + j0;
+            if (fine && ev_begin(c, 4)) return 1;
 #define LAUNCH_E(CM)                                                                                           \
-    hipLaunchKernelGGL(k2_estep<CM>, dim3((unsigned)(((n_jobs + 7) / 8) * 8)), dim3(64), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm,    \
-                       c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),               \
-                       c->j_K.as<int32_t>(), c->j_fixed.as<int32_t>(), c->j_a.as<int32_t>(),                   \
-                       c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(), S,                  \
-                       c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                    \
+    hipLaunchKernelGGL(k2_estep<CM>, dim3((unsigned)(((ngj + 7) / 8) * 8)), dim3(64), 0, st,                   \
+                       c->d_desc.as<UtrDesc>(), c->prm, c->d_cnt.as<double>(), c->d_M.as<double>(), kmax,      \
+                       c->j_utr.as<int32_t>(), c->j_K.as<int32_t>(), c->j_fixed.as<int32_t>(),                 \
+                       c->j_a.as<int32_t>(), c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(), \
+                       S, c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                 \
                        c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                    \
-                       c->d_counters.as<unsigned long long>(), r, n_jobs, dbg_e)
-        if (kmax + 1 <= 4) LAUNCH_E(4);
-        else if (kmax + 1 <= 8) LAUNCH_E(8);
-        else if (kmax + 1 <= 12) LAUNCH_E(12);
-        else if (kmax + 1 <= 16) LAUNCH_E(16);
-        else if (kmax + 1 <= 24) LAUNCH_E(24);
-        else LAUNCH_E(32);
+                       c->d_counters.as<unsigned long long>(), r, jl, ngj, dbg_e)
+            if (kmax + 1 <= 4) LAUNCH_E(4);
+            else if (kmax + 1 <= 8) LAUNCH_E(8);
+            else if (kmax + 1 <= 12) LAUNCH_E(12);
+            else if (kmax + 1 <= 16) LAUNCH_E(16);
+            else if (kmax + 1 <= 24) LAUNCH_E(24);
+            else LAUNCH_E(32);
 #undef LAUNCH_E
-        HIPCHK(hipGetLastError());
-        if (fine && ev_end(c, 4)) return 1;
-        if (r < nround && any_m) {
-            if (fine && ev_begin(c, 5)) return 1;
-            hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((c->n_utr + 7) / 8) * 8 * tiles_max)), dim3(256), 0, c->stream,
-                               c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->n_utr, tiles_max, c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.voff,
-                               S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, dbg);
             HIPCHK(hipGetLastError());
-            if (fine && ev_end(c, 5)) return 1;
+            if (fine && ev_end(c, 4)) return 1;
+            if (r < nround && any_m) {
+                if (fine && ev_begin(c, 5)) return 1;
+                const int nu = u1 - u0;
+                hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max)), dim3(256), 0, st,
+                                   c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), u0, nu, tiles_max,
+                                   c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.voff, S.rd_m, S.rd_lo,
+                                   S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, dbg);
+                HIPCHK(hipGetLastError());
+                if (fine && ev_end(c, 5)) return 1;
+            }
         }
         if (r < nround && (r & 3) == 3) {
             // early exit: no job executed a round since the last probe -> every job has been finalised
             unsigned long long executed = 0;
+            if (split) HIPCHK(hipStreamSynchronize(c->stream2));
             HIPCHK(hipMemcpyAsync(&executed, c->d_counters.as<unsigned long long>() + 3, sizeof(executed),
                                   hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -962,6 +990,13 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             fprintf(stderr, "\n");
             HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
         }
+    }
+    if (split) {
+        HIPCHK(hipEventRecord(ev_join, c->stream2));
+        HIPCHK(hipStreamWaitEvent(c->stream, ev_join, 0));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipEventDestroy(ev_fork);
+        (void)hipEventDestroy(ev_join);
     }
     if (dbg) (void)hipFree(dbg);
     return 0;
@@ -990,6 +1025,7 @@ int scape_hip_create(int device, scape_hip_ctx **out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipStreamCreate(&c->stream2));
     if (c->d_counters.ensure(4 * sizeof(unsigned long long))) return 1;
     *out = c;
     return 0;
@@ -1030,6 +1066,7 @@ int scape_hip_destroy(scape_hip_ctx *c) {
             (void)hipEventDestroy(e.b);
         }
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream2);
     delete c;
     return 0;
 }
