@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utrs", type=int, default=256, help="UTRs per GPU per step")
+    ap.add_argument("--utrs", type=int, default=512, help="UTRs per GPU per step")
     ap.add_argument("--reads", type=int, default=2000)
     ap.add_argument("--kcap", type=int, default=10)
     ap.add_argument("--base-seed", type=int, default=20250225)

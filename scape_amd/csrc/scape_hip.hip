@@ -55,6 +55,7 @@ struct UtrDesc {
     int64_t at_off;     // offset (f64) of AT / V  [T][Np]
     int64_t m_off;      // offset (f64) of M       [T][B][Np]
     int64_t log_off;    // first entry in the log-domain bin list
+    int64_t tile_off;   // first entry of this UTR in the per-tile extent table (64-row tiles of M)
     int32_t N, Np, T, n_log;
     double unif_ll, L, min_theta;
 };
@@ -366,6 +367,44 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
         for (int w = 0; w < W; ++w) sum += exp(Au[(size_t)(a + w) * d.Np + n] + gj[w] - Gj - mx);
         Mi[(size_t)j * d.Np + n] = log(sum) + mx;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile extents: bins are ordered by read start, so each tensor row (theta_a, beta_b) is finite on a
+// prefix of the bins and holds the sentinel (read impossible: x + l > theta) on the rest - 35-50 % of
+// all entries.  For every 64-row tile this records one past the last bin that is finite in ANY of its
+// rows (rounded up to 16).  Beyond it every row of the tile is the sentinel, and the M-step replaces
+// that part of the dot product by SENT * sum(v) instead of streaming it.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_extent(const UtrDesc *__restrict__ descs, int B,
+                                                     const double *__restrict__ M,
+                                                     int32_t *__restrict__ tile_nend) {
+    __shared__ int s_max;
+    const UtrDesc d = descs[blockIdx.y];
+    const int nrows = d.T * B, row0 = blockIdx.x * 64;
+    if (row0 >= nrows) return;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int best = 0;
+    for (int rr = wave; rr < 64; rr += 4) {
+        const int row = row0 + rr;
+        if (row >= nrows) break;
+        const double *Mr = M + (size_t)d.m_off + (size_t)row * d.Np;
+        for (int base = ((d.N - 1) / 64) * 64; base >= 0; base -= 64) {   // scan from the end
+            const int n = base + lane;
+            const bool fin = (n < d.N) && (Mr[n] != SENT);
+            const unsigned long long m = __ballot(fin);
+            if (m) {
+                best = max(best, base + 64 - (int)__builtin_clzll(m));
+                break;
+            }
+            if (base + 64 <= best) break;   // cannot improve on what another row already found
+        }
+    }
+    if (lane == 0) atomicMax(&s_max, best);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_nend[d.tile_off + blockIdx.x] = min(d.Np, (s_max + 15) & ~15);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -743,7 +782,9 @@ struct scape_hip_ctx {
     int64_t n_bins = 0;
     std::vector<UtrDesc> h_desc;
     size_t at_total = 0, m_total = 0;
-    DevBuf d_x, d_l, d_r, d_pa, d_cnt, d_theta, d_desc, d_loglist, d_AT, d_V, d_M, d_err, d_counters;
+    DevBuf d_x, d_l, d_r, d_pa, d_cnt, d_theta, d_desc, d_loglist, d_AT, d_V, d_M, d_err, d_counters, d_tile_nend;
+    int tiles_max_all = 1;
+    size_t tiles_total = 0;
     DevBuf j_utr, j_K, j_fixed, j_a, j_b, j_ws, j_karr, j_ao, j_bo, j_wso, j_bic, j_nlb, j_lb;
     DevBuf l_utr, l_K, l_a, l_b, l_ws, l_labels;
     // lock-step EM state (em_lockstep.inc)
@@ -967,7 +1008,8 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                 hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max)), dim3(256), 0, st,
                                    c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), u0, nu, tiles_max,
                                    c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.voff, S.rd_m, S.rd_lo,
-                                   S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, dbg);
+                                   S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row,
+                                   c->d_tile_nend.as<int32_t>(), dbg);
                 HIPCHK(hipGetLastError());
                 if (fine && ev_end(c, 5)) return 1;
             }
@@ -1040,7 +1082,7 @@ int scape_hip_device_name(scape_hip_ctx *c, char *buf, int buflen) {
 int scape_hip_batch_free(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
     if (set_device(c)) return 1;
-    DevBuf *all[] = {&c->d_x, &c->d_l, &c->d_r, &c->d_pa, &c->d_cnt, &c->d_theta, &c->d_desc, &c->d_loglist,
+    DevBuf *all[] = {&c->d_tile_nend, &c->d_x, &c->d_l, &c->d_r, &c->d_pa, &c->d_cnt, &c->d_theta, &c->d_desc, &c->d_loglist,
                      &c->d_AT, &c->d_V, &c->d_M, &c->j_utr, &c->j_K, &c->j_fixed, &c->j_a, &c->j_b, &c->j_ws,
                      &c->j_karr, &c->j_ao, &c->j_bo, &c->j_wso, &c->j_bic, &c->j_nlb, &c->j_lb, &c->l_utr,
                      &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels, &c->e_ia, &c->e_ib, &c->e_sia, &c->e_sib,
@@ -1213,8 +1255,8 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
 
     c->h_desc.assign(n_utr, UtrDesc());
     std::vector<int32_t> loglist;
-    size_t at_total = 0, m_total = 0;
-    int T_max = 0, Np_max = 0, W_max = 1;
+    size_t at_total = 0, m_total = 0, tiles_total = 0;
+    int T_max = 0, Np_max = 0, W_max = 1, tiles_max_all = 1;
     for (int u = 0; u < n_utr; ++u) {
         UtrDesc &d = c->h_desc[u];
         const int64_t N = bin_off[u + 1] - bin_off[u], T = theta_off[u + 1] - theta_off[u];
@@ -1230,6 +1272,12 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
         d.at_off = (int64_t)at_total;
         d.m_off = (int64_t)m_total;
         d.log_off = (int64_t)loglist.size();
+        d.tile_off = (int64_t)tiles_total;
+        {
+            const int nt = (int)((T * p->n_beta + 63) / 64);
+            tiles_total += (size_t)nt;
+            tiles_max_all = std::max(tiles_max_all, nt);
+        }
         for (int64_t n = 0; n < N; ++n)
             if (!std::isnan(pa[bin_off[u] + n]) || !std::isnan(r[bin_off[u] + n])) loglist.push_back((int32_t)n);
         d.n_log = (int)(loglist.size() - (size_t)d.log_off);
@@ -1251,10 +1299,12 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
     c->W_max = W_max;
     c->at_total = at_total;
     c->m_total = m_total;
+    c->tiles_total = tiles_total;
+    c->tiles_max_all = tiles_max_all;
     if (c->d_x.ensure(nb * 8) || c->d_l.ensure(nb * 8) || c->d_r.ensure(nb * 8) || c->d_pa.ensure(nb * 8) ||
         c->d_cnt.ensure(nb * 8) || c->d_theta.ensure(nt * 8) || c->d_desc.ensure(n_utr * sizeof(UtrDesc)) ||
         c->d_loglist.ensure(loglist.size() * 4) || c->d_AT.ensure(at_total * 8) || c->d_V.ensure(at_total * 8) ||
-        c->d_M.ensure(m_total * 8))
+        c->d_M.ensure(m_total * 8) || c->d_tile_nend.ensure(tiles_total * 4))
         return 1;
     HIPCHK(hipMemcpyAsync(c->d_x.p, x, nb * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_l.p, l, nb * 8, hipMemcpyHostToDevice, c->stream));
@@ -1297,6 +1347,9 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
                        c->d_pa.as<double>(), c->d_theta.as<double>(), c->d_loglist.as<int32_t>(),
                        c->d_AT.as<double>(), c->d_V.as<double>(), c->d_M.as<double>(), 0))
         return 1;
+    hipLaunchKernelGGL(k_tile_extent, dim3(c->tiles_max_all, c->n_utr), dim3(256), 0, c->stream, c->d_desc.as<UtrDesc>(),
+                       c->prm.B, c->d_M.as<double>(), c->d_tile_nend.as<int32_t>());
+    HIPCHK(hipGetLastError());
     if (ev_end(c, 1)) return 1;
     if (check_err_flag(c, "batch_build")) return 1;
     c->built = true;
