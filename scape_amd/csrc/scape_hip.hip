@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                                                  const double *__restrict__ AT,
                                                  const double *__restrict__ V,
                                                  double *__restrict__ M, int Wmax, int all_log,
-                                                 int *__restrict__ err_flag, int n_utr, int T_max) {
+                                                 int *__restrict__ err_flag, int n_utr, int T_max, int dbg) {
     extern __shared__ double sm[];
     // blocks b and b+8 share an XCD: all grid points of a UTR go to one XCD so its V rows (each is
     // read by ~43 neighbouring alphas) are fetched into one L2 only.  Placement only affects speed.
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
 
     double *Mi = M + (size_t)d.m_off + (size_t)i * B * d.Np;
     // ---- linear-domain path -----------------------------------------------------------------
-    if (!all_log) {
+    if (!all_log && dbg != 1 && dbg != 3) {
         const double *Vu = V + (size_t)d.at_off;
         for (int n = tid; n < d.Np; n += blockDim.x) {
             if (n >= d.N) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                 }
 #pragma unroll
                 for (int j = 0; j < BMAX; ++j)
-                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? log(acc[j]) : SENT;
+                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? ((dbg == 4) ? acc[j] : log(acc[j])) : SENT;
             } else {
                 for (int j = 0; j < B; ++j) {
                     double acc = 0.0;
@@ -345,12 +345,12 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                 }
             }
         }
-    } else {
+    } else if (all_log) {
         for (int n = d.N + tid; n < d.Np; n += blockDim.x)
             for (int j = 0; j < B; ++j) Mi[(size_t)j * d.Np + n] = 0.0;
     }
     // ---- log-domain path (cal_res_kernel, taichi_core.py:172-179) ------------------------------
-    const int n_log = all_log ? d.N : d.n_log;
+    const int n_log = (dbg == 2 || dbg == 3) ? 0 : (all_log ? d.N : d.n_log);
     const double *Au = AT + (size_t)d.at_off;
     for (int item = tid; item < n_log * B; item += blockDim.x) {
         const int j = item / n_log, q = item - j * n_log;
@@ -868,13 +868,14 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
     HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
     const size_t lds = ((size_t)2 * prm.B * Wmax + prm.B) * sizeof(double) + (size_t)2 * prm.B * sizeof(int);
     if (lds > 150 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
+    const int dbg_b = getenv("SCAPE_HIP_DBG_B") ? atoi(getenv("SCAPE_HIP_DBG_B")) : 0;   // timing experiments only
     dim3 grid((unsigned)(((n_utr + 7) / 8) * 8 * T_max));
     if (prm.B <= 16)
         hipLaunchKernelGGL(k_phase_b<16>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, dbg_b);
     else
         hipLaunchKernelGGL(k_phase_b<1>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, dbg_b);
     HIPCHK(hipGetLastError());
     return 0;
 }
