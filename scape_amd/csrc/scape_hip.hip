@@ -27,6 +27,7 @@
 #define SENT SCAPE_SENT
 #define PI_REF 3.141592653589793  // taichi_core.py:9
 #define PITCH 16                  // row pitch granule (f64 elements) -> 128-B aligned rows
+#define TILE_ROWS 64               // tensor rows per M-step tile (= MT_ROWS of em_lockstep.inc)
 #define EM_THREADS 256
 #define EM_WAVES (EM_THREADS / 64)
 
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                                                  const double *__restrict__ AT,
                                                  const double *__restrict__ V,
                                                  double *__restrict__ M, int Wmax, int all_log,
-                                                 int *__restrict__ err_flag, int n_utr, int T_max, int dbg) {
+                                                 int *__restrict__ err_flag, int n_utr, int T_max) {
     extern __shared__ double sm[];
     // blocks b and b+8 share an XCD: all grid points of a UTR go to one XCD so its V rows (each is
     // read by ~43 neighbouring alphas) are fetched into one L2 only.  Placement only affects speed.
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
 
     double *Mi = M + (size_t)d.m_off + (size_t)i * B * d.Np;
     // ---- linear-domain path -----------------------------------------------------------------
-    if (!all_log && dbg != 1 && dbg != 3) {
+    if (!all_log) {
         const double *Vu = V + (size_t)d.at_off;
         for (int n = tid; n < d.Np; n += blockDim.x) {
             if (n >= d.N) {
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                 }
 #pragma unroll
                 for (int j = 0; j < BMAX; ++j)
-                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? ((dbg == 4) ? acc[j] : log(acc[j])) : SENT;
+                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? log(acc[j]) : SENT;
             } else {
                 for (int j = 0; j < B; ++j) {
                     double acc = 0.0;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
             for (int j = 0; j < B; ++j) Mi[(size_t)j * d.Np + n] = 0.0;
     }
     // ---- log-domain path (cal_res_kernel, taichi_core.py:172-179) ------------------------------
-    const int n_log = (dbg == 2 || dbg == 3) ? 0 : (all_log ? d.N : d.n_log);
+    const int n_log = all_log ? d.N : d.n_log;
     const double *Au = AT + (size_t)d.at_off;
     for (int item = tid; item < n_log * B; item += blockDim.x) {
         const int j = item / n_log, q = item - j * n_log;
@@ -381,13 +382,13 @@ __global__ __launch_bounds__(256) void k_tile_extent(const UtrDesc *__restrict__
                                                      int32_t *__restrict__ tile_nend) {
     __shared__ int s_max;
     const UtrDesc d = descs[blockIdx.y];
-    const int nrows = d.T * B, row0 = blockIdx.x * 64;
+    const int nrows = d.T * B, row0 = blockIdx.x * TILE_ROWS;
     if (row0 >= nrows) return;
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int best = 0;
-    for (int rr = wave; rr < 64; rr += 4) {
+    for (int rr = wave; rr < TILE_ROWS; rr += 4) {
         const int row = row0 + rr;
         if (row >= nrows) break;
         const double *Mr = M + (size_t)d.m_off + (size_t)row * d.Np;
@@ -868,14 +869,13 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
     HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
     const size_t lds = ((size_t)2 * prm.B * Wmax + prm.B) * sizeof(double) + (size_t)2 * prm.B * sizeof(int);
     if (lds > 150 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
-    const int dbg_b = getenv("SCAPE_HIP_DBG_B") ? atoi(getenv("SCAPE_HIP_DBG_B")) : 0;   // timing experiments only
     dim3 grid((unsigned)(((n_utr + 7) / 8) * 8 * T_max));
     if (prm.B <= 16)
         hipLaunchKernelGGL(k_phase_b<16>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, dbg_b);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
     else
         hipLaunchKernelGGL(k_phase_b<1>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, dbg_b);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -956,7 +956,6 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
     }
     const bool fine = getenv("SCAPE_HIP_ROUND_TIMING") != nullptr;
-    const int dbg_e = getenv("SCAPE_HIP_DBG_E") ? atoi(getenv("SCAPE_HIP_DBG_E")) : 0;   // timing experiments only
     bool any_m = false;   // fixed-inference jobs (mstep_fixed) have no grid arg-max
     for (size_t j = 0; j < nj && !any_m; ++j) any_m = job_fixed[j] == 0;
     // Two halves of the UTRs advance on two streams: the E-step is f64-VALU work, the M-step an HBM stream,
@@ -993,7 +992,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                        c->j_a.as<int32_t>(), c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(), \
                        S, c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                 \
                        c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                    \
-                       c->d_counters.as<unsigned long long>(), r, jl, ngj, dbg_e)
+                       c->d_counters.as<unsigned long long>(), r, jl, ngj)
             if (kmax + 1 <= 4) LAUNCH_E(4);
             else if (kmax + 1 <= 8) LAUNCH_E(8);
             else if (kmax + 1 <= 12) LAUNCH_E(12);
@@ -1275,7 +1274,7 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
         d.log_off = (int64_t)loglist.size();
         d.tile_off = (int64_t)tiles_total;
         {
-            const int nt = (int)((T * p->n_beta + 63) / 64);
+            const int nt = (int)((T * p->n_beta + TILE_ROWS - 1) / TILE_ROWS);
             tiles_total += (size_t)nt;
             tiles_max_all = std::max(tiles_max_all, nt);
         }
