@@ -1474,10 +1474,23 @@ int scape_hip_batch_labels(scape_hip_ctx *c, int32_t n_sel, int32_t kmax, const 
 #undef LAUNCH_LAB
     HIPCHK(hipGetLastError());
     if (ev_end(c, 3)) return 1;
-    for (int j = 0; j < n_sel; ++j) {
-        const UtrDesc &d = c->h_desc[sel_utr[j]];
-        HIPCHK(hipMemcpyAsync(labels_out + d.bin_off, c->l_labels.as<int32_t>() + d.bin_off, (size_t)d.N * 4,
-                              hipMemcpyDeviceToHost, c->stream));
+    // copy back only the selected UTRs' bins; contiguous runs of selected UTRs go in one transfer
+    {
+        std::vector<char> sel(c->n_utr, 0);
+        for (int j = 0; j < n_sel; ++j) sel[sel_utr[j]] = 1;
+        int u = 0;
+        while (u < c->n_utr) {
+            if (!sel[u]) {
+                ++u;
+                continue;
+            }
+            int v = u;
+            while (v + 1 < c->n_utr && sel[v + 1]) ++v;
+            const int64_t b0 = c->h_desc[u].bin_off, b1 = c->h_desc[v].bin_off + c->h_desc[v].N;
+            HIPCHK(hipMemcpyAsync(labels_out + b0, c->l_labels.as<int32_t>() + b0, (size_t)(b1 - b0) * 4,
+                                  hipMemcpyDeviceToHost, c->stream));
+            u = v + 1;
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
