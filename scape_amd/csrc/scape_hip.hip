@@ -316,7 +316,43 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
 
     double *Mi = M + (size_t)d.m_off + (size_t)i * B * d.Np;
     // ---- linear-domain path -----------------------------------------------------------------
-    if (!all_log) {
+    // out[j][n] = sum_w p[j][w] * V[w][n] is a [16 x W] x [W x N] product: on the f64 matrix cores one
+    // v_mfma_f64_16x16x4_f64 covers 16 betas (13 used) x 16 bins x 4 taps.  A = weights from LDS (lane l:
+    // beta l&15, tap l>>4), B = V straight from global/L2 (lane l: tap l>>4, bin l&15), D lane l reg q:
+    // beta (l>>4)+4q, bin l&15.
+    if (!all_log && BMAX == 16) {
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int WP = ((Wmax + 3) & ~3) + 1;                     // odd pitch: conflict-light fragment reads
+        double *pm = reinterpret_cast<double *>(hi + B + (B & 1)); // [16][WP], zero outside window / beyond B
+        for (int e = tid; e < 16 * WP; e += blockDim.x) {
+            const int j = e / WP, w = e - j * WP;
+            pm[e] = (j < B && w < Wmax) ? p[(size_t)j * Wmax + w] : 0.0;
+        }
+        __syncthreads();
+        const double *Vu = V + (size_t)d.at_off;
+        const int lane = tid & 63, wave = tid >> 6, kq = lane >> 4, rc = lane & 15;
+        const int nblocks = d.Np >> 4;
+        for (int nb = wave; nb < nblocks; nb += 4) {
+            const int n = nb * 16 + rc;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int w0 = 0; w0 < Wall; w0 += 4) {
+                const int wr = min(lo_all + w0 + kq, d.T - 1);     // past the window the weight is 0
+                const double bv = Vu[(size_t)wr * d.Np + n];
+                const double av = pm[rc * WP + w0 + kq];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+            if (n >= d.N) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (kq + 4 * q < B) Mi[(size_t)(kq + 4 * q) * d.Np + n] = 0.0;
+            } else if (isnan(pa[d.bin_off + n]) && isnan(r[d.bin_off + n])) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (kq + 4 * q < B) Mi[(size_t)(kq + 4 * q) * d.Np + n] = (acc[q] > 0.0) ? log(acc[q]) : SENT;
+            }
+        }
+    } else if (!all_log) {
         const double *Vu = V + (size_t)d.at_off;
         for (int n = tid; n < d.Np; n += blockDim.x) {
             if (n >= d.N) {
@@ -867,7 +903,8 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
                           const double *d_V, double *d_M, int all_log) {
     if (c->d_err.ensure(sizeof(int))) return 1;
     HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
-    const size_t lds = ((size_t)2 * prm.B * Wmax + prm.B) * sizeof(double) + (size_t)2 * prm.B * sizeof(int);
+    const size_t lds = ((size_t)2 * prm.B * Wmax + prm.B) * sizeof(double) + (size_t)2 * (prm.B + 1) * sizeof(int) +
+                       (size_t)16 * (((Wmax + 3) & ~3) + 1) * sizeof(double);
     if (lds > 150 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
     dim3 grid((unsigned)(((n_utr + 7) / 8) * 8 * T_max));
     if (prm.B <= 16)
