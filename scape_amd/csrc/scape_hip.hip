@@ -826,7 +826,7 @@ struct scape_hip_ctx {
     DevBuf l_utr, l_K, l_a, l_b, l_ws, l_labels;
     // lock-step EM state (em_lockstep.inc)
     DevBuf e_ia, e_ib, e_sia, e_sib, e_ws, e_slw, e_lb, e_ell, e_nlb, e_status, e_rdk, e_rdlo, e_rdhi, e_rdm,
-        e_rdlw, e_rdsv, e_rdn0, e_rdn1, e_V, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist;
+        e_rdlw, e_rdsv, e_rdn0, e_rdn1, e_V, e_Vsuf, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist;
     std::vector<EventPair> ev[6];
     double ms_acc[6] = {0, 0, 0, 0, 0, 0};
     int n_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -953,7 +953,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         c->e_sib.ensure(nj * kmax * 4) || c->e_ws.ensure(nj * (kmax + 1) * 8) || c->e_slw.ensure(nj * (kmax + 1) * 8) ||
         c->e_lb.ensure(nj * 8) || c->e_ell.ensure(nj * 8) || c->e_nlb.ensure(nj * 4) || c->e_status.ensure(nj * 4) ||
         c->e_rdk.ensure(nj * 4) || c->e_rdlo.ensure(nj * 4) || c->e_rdhi.ensure(nj * 4) || c->e_rdm.ensure(nj * 4) ||
-        c->e_rdlw.ensure(nj * 8) || c->e_rdsv.ensure(nj * 8) || c->e_rdn0.ensure(nj * 4) || c->e_rdn1.ensure(nj * 4) || c->e_V.ensure(vtot * 8) || c->e_voff.ensure(nj * 8) ||
+        c->e_rdlw.ensure(nj * 8) || c->e_rdsv.ensure(nj * 8) || c->e_rdn0.ensure(nj * 4) || c->e_rdn1.ensure(nj * 4) || c->e_V.ensure(vtot * 8) || c->e_Vsuf.ensure((vtot / 16 + nj + 1) * 8) || c->e_voff.ensure(nj * 8) ||
         c->e_ptscore.ensure(pttot * 8) || c->e_ptrow.ensure(pttot * 4) || c->e_ptoff.ensure(nj * 8) ||
         c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4))
         return 1;
@@ -982,6 +982,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     S.rd_n0 = c->e_rdn0.as<int32_t>();
     S.rd_n1 = c->e_rdn1.as<int32_t>();
     S.V = c->e_V.as<double>();
+    S.Vsuf = c->e_Vsuf.as<double>();
     S.voff = c->e_voff.as<int64_t>();
     S.pt_score = c->e_ptscore.as<double>();
     S.pt_row = c->e_ptrow.as<int32_t>();
@@ -1044,7 +1045,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                 const int nu = u1 - u0;
                 hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max)), dim3(256), 0, st,
                                    c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), u0, nu, tiles_max,
-                                   c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.voff, S.rd_m, S.rd_lo,
+                                   c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo,
                                    S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row,
                                    c->d_tile_nend.as<int32_t>(), dbg);
                 HIPCHK(hipGetLastError());
@@ -1124,7 +1125,7 @@ int scape_hip_batch_free(scape_hip_ctx *c) {
                      &c->j_karr, &c->j_ao, &c->j_bo, &c->j_wso, &c->j_bic, &c->j_nlb, &c->j_lb, &c->l_utr,
                      &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels, &c->e_ia, &c->e_ib, &c->e_sia, &c->e_sib,
                      &c->e_ws, &c->e_slw, &c->e_lb, &c->e_ell, &c->e_nlb, &c->e_status, &c->e_rdk, &c->e_rdlo,
-                     &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_rdn0, &c->e_rdn1, &c->e_V, &c->e_voff, &c->e_ptscore,
+                     &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_rdn0, &c->e_rdn1, &c->e_V, &c->e_Vsuf, &c->e_voff, &c->e_ptscore,
                      &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist};
     for (DevBuf *b : all) b->release();
     c->loaded = c->built = false;
