@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # HBM bytes per k2_mstep launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) at
 # the default workload (512 UTRs x 2k reads per step); see profiles/README.md.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 11.3e9
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 11.2e9
 
 
 def parse():
