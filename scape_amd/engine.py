@@ -25,7 +25,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import Params, check, f64, i32, ptr, P_i32, P_i64, P_i8
-from .host import N_ROUND, N_TRIAL, Sampler, UtrPrep
+from . import _hostlib
+from .host import N_ROUND, N_TRIAL, FastSampler, Sampler, UtrPrep
 
 
 @dataclass
@@ -331,7 +332,7 @@ class Engine:
         results = [UtrResult(prep=q) for q in preps]
         if seeds is None:
             seeds = [(seed + i) % (2 ** 32) for i in range(len(preps))]
-        shared = Sampler(rs if rs is not None else np.random.RandomState(seed)) if rng_mode == "reference" else None
+        shared = FastSampler(rs if rs is not None else np.random.RandomState(seed)) if rng_mode == "reference" else None
         self.traces = [[] for _ in preps] if keep_trace else None
         for wave in self.waves(preps):
             wp = [preps[i] for i in wave]
@@ -340,7 +341,7 @@ class Engine:
                 batch.build()
                 sweeps = []
                 for u, gi in enumerate(wave):
-                    smp = shared if shared is not None else Sampler(np.random.RandomState(seeds[gi]))
+                    smp = shared if shared is not None else FastSampler(np.random.RandomState(seeds[gi]))
                     sweeps.append(_Sweep(u, preps[gi], smp, re_run_mode, self.traces[gi] if keep_trace else None))
                 if rng_mode == "reference":
                     for sw in sweeps:
@@ -354,6 +355,8 @@ class Engine:
                 out = self.process(batch, wp, plan, re_run_mode)
             for (fit, lab, nj), gi in zip(out, wave):
                 results[gi].fit, results[gi].labels_bin, results[gi].n_jobs = fit, lab, nj
+        if shared is not None:
+            shared.rs                      # hand the advanced stream back to the caller's RandomState
         return results
 
     # ---- several reference-RNG streams at once (one stream = one chunk file) --------------------------
@@ -368,7 +371,7 @@ class Engine:
                 flat.append(q)
                 owner.append(si)
         results = [UtrResult(prep=q) for q in flat]
-        samplers = [Sampler(np.random.RandomState(seed)) for _p, seed in streams]
+        samplers = [FastSampler(np.random.RandomState(seed)) for _p, seed in streams]
         # streams advance monotonically, so waves are cut over the flat list in round-robin stream order
         order = []
         cursors = [0] * len(streams)
@@ -429,10 +432,9 @@ class Engine:
 
     # ---- fully batched path (per-UTR RNG): pre-drawn job tables + vectorised selection -------------
     @staticmethod
-    def plan(preps, seeds):
-        """Draw every restart of the first K sweep (init_para + gen_k_arr, reference order) for each
-        UTR from its own RandomState.  Returns the packed job tables plus the RNG states left
-        behind (prune / re-run draws continue from them)."""
+    def plan_python(preps, seeds):
+        """The plan drawn with numpy's RandomState itself (scape_amd/host.py::Sampler): readable twin of
+        :meth:`plan`, used for the UTRs the native sampler declines and by tests/test_host.py."""
         jobs, samplers = [], []
         for u, (q, sd) in enumerate(zip(preps, seeds)):
             smp = Sampler(np.random.RandomState(sd))
@@ -443,22 +445,83 @@ class Engine:
             samplers.append(smp)
         spans = np.zeros(len(preps) + 1, dtype=np.int64)
         np.cumsum([(q.p["n_max_apa"] - q.p["n_min_apa"] + 1) * N_TRIAL for q in preps], out=spans[1:])
-        states = [s.rs.get_state() for s in samplers]
+        states = np.stack([_hostlib.state_from_numpy(s.rs.get_state()) for s in samplers])
         # rm_component draws (init_ws + gen_k_arr, :843 -> :709 -> :720) for every possible K' < n_max,
         # each continuing the UTR's stream from the state the sweep left behind
         kcap = max(q.p["n_max_apa"] for q in preps)
         prune_w = np.zeros((len(preps), kcap, kcap + 1))
         prune_ka = np.zeros((len(preps), kcap, N_ROUND), dtype=np.int8)
-        prune_states = [[None] * kcap for _ in preps]
+        prune_states = np.zeros((len(preps), kcap, _hostlib.STATE_WORDS), dtype=np.uint32)
         rs = np.random.RandomState(0)
         for u, q in enumerate(preps):
             for Kp in range(q.p["n_max_apa"]):
-                rs.set_state(states[u])
+                rs.set_state(_hostlib.state_to_numpy(states[u]))
                 smp = Sampler(rs)
                 prune_w[u, Kp, :Kp + 1] = smp.init_ws(Kp, q.p["max_unif_ws"])
                 prune_ka[u, Kp] = smp.k_arr(Kp)
-                prune_states[u][Kp] = rs.get_state()
+                prune_states[u, Kp] = _hostlib.state_from_numpy(rs.get_state())
         return dict(main=pack_jobs(jobs), spans=spans, states=states, prune_w=prune_w, prune_ka=prune_ka,
+                    prune_states=prune_states)
+
+    @staticmethod
+    def plan(preps, seeds, n_threads=None):
+        """Draw every restart of the first K sweep (init_para + gen_k_arr, reference order) for each
+        UTR from its own RandomState(seed), plus the tables rm_component would draw for every possible
+        K' and the generator states left behind (prune / re-run draws continue from them).  Drawn by
+        libscape_host.so (include/scape_host.h::scape_host_plan) on the host threads; numbers are
+        those of :meth:`plan_python`."""
+        H = _hostlib
+        lib = H.load_library()
+        U = len(preps)
+        n_max = i32([q.p["n_max_apa"] for q in preps])
+        n_min = i32([q.p["n_min_apa"] for q in preps])
+        spans = np.zeros(U + 1, dtype=np.int64)
+        np.cumsum((n_max - n_min + 1).astype(np.int64) * N_TRIAL, out=spans[1:])
+        J, kmax = int(spans[-1]), max(1, int(n_max.max()))
+        kcap = kmax
+        peak_off = np.zeros(U + 1, dtype=np.int64)
+        np.cumsum([len(q.peaks) for q in preps], out=peak_off[1:])
+        theta_off = np.zeros(U + 1, dtype=np.int64)
+        np.cumsum([len(q.theta) for q in preps], out=theta_off[1:])
+        f64 = lambda xs: np.ascontiguousarray(np.concatenate(xs) if len(xs) else np.zeros(0), dtype=np.float64)  # noqa: E731
+        peaks, peak_w = f64([q.peaks for q in preps]), f64([q.peak_w for q in preps])
+        theta = f64([q.theta for q in preps])
+        Ls, n_beta = i32([q.L for q in preps]), i32([len(q.betas) for q in preps])
+        scale = np.array([5 * q.p["beta_step"] for q in preps], dtype=np.float64)
+        mxu = np.array([q.p["max_unif_ws"] for q in preps], dtype=np.float64)
+        sd = np.array([int(x) % (2 ** 32) for x in seeds], dtype=np.uint32)
+        pj = PackedJobs(np.zeros(J, np.int32), np.zeros(J, np.int32), np.zeros(J, np.int32),
+                        np.zeros((J, kmax), np.int32), np.zeros((J, kmax), np.int32),
+                        np.zeros((J, kmax + 1), np.float64), np.zeros((J, N_ROUND), np.int8))
+        states = np.zeros((U, H.STATE_WORDS), dtype=np.uint32)
+        prune_w = np.zeros((U, kcap, kcap + 1))
+        prune_ka = np.zeros((U, kcap, N_ROUND), dtype=np.int8)
+        prune_states = np.zeros((U, kcap, H.STATE_WORDS), dtype=np.uint32)
+        status = np.ones(U, dtype=np.int32)
+        ok_k = kmax <= H.MAX_K
+        if ok_k and U:
+            A = H.PlanArgs(U, n_threads or H.host_threads(), N_TRIAL, N_ROUND, kmax, kcap,
+                           H.ptr(sd, H.P_u32), H.ptr(peak_off, H.P_i64), H.ptr(peaks, H.P_d), H.ptr(peak_w, H.P_d),
+                           H.ptr(theta_off, H.P_i64), H.ptr(theta, H.P_d),
+                           H.ptr(Ls, H.P_i32), H.ptr(n_max, H.P_i32), H.ptr(n_min, H.P_i32), H.ptr(n_beta, H.P_i32),
+                           H.ptr(scale, H.P_d), H.ptr(mxu, H.P_d), H.ptr(spans, H.P_i64),
+                           H.ptr(pj.ju, H.P_i32), H.ptr(pj.jk, H.P_i32), H.ptr(pj.a, H.P_i32), H.ptr(pj.b, H.P_i32),
+                           H.ptr(pj.w, H.P_d), H.ptr(pj.ka, H.P_i8), H.ptr(states, H.P_u32), H.ptr(prune_w, H.P_d),
+                           H.ptr(prune_ka, H.P_i8), H.ptr(prune_states, H.P_u32), H.ptr(status, H.P_i32))
+            if lib.scape_host_plan(ctypes.byref(A)):
+                status[:] = 1
+        for u in np.nonzero(status)[0]:            # declined by the native path: numpy draws them
+            u = int(u)
+            one = Engine.plan_python([preps[u]], [int(sd[u])])
+            lo, hi, m, k1 = int(spans[u]), int(spans[u + 1]), one["main"], one["main"].kmax
+            pj.ju[lo:hi], pj.jk[lo:hi] = u, m.jk
+            pj.a[lo:hi], pj.b[lo:hi], pj.w[lo:hi] = 0, 0, 0.0
+            pj.a[lo:hi, :k1], pj.b[lo:hi, :k1], pj.w[lo:hi, :k1 + 1], pj.ka[lo:hi] = m.a, m.b, m.w, m.ka
+            states[u] = one["states"][0]
+            prune_w[u], prune_ka[u], prune_states[u] = 0.0, 0, 0
+            prune_w[u, :k1, :k1 + 1], prune_ka[u, :k1] = one["prune_w"][0], one["prune_ka"][0]
+            prune_states[u, :k1] = one["prune_states"][0]
+        return dict(main=pj, spans=spans, states=states, prune_w=prune_w, prune_ka=prune_ka,
                     prune_states=prune_states)
 
     def process(self, batch, preps, plan, re_run_mode=True):
@@ -530,11 +593,11 @@ class Engine:
                 if u in refit:
                     rpj, rout, i = refit.pop(u)
                     best = batch.fit_at(rpj, rout, i)
-                    rs.set_state(plan["prune_states"][u][best.K])
+                    rs.set_state(_hostlib.state_to_numpy(plan["prune_states"][u][best.K]))
                 else:
                     best = batch.fit_at(pj, out, int(win[u]))
-                    rs.set_state(plan["states"][u])
-                sw = _Sweep(u, preps[u], Sampler(rs), re_run_mode)
+                    rs.set_state(_hostlib.state_to_numpy(plan["states"][u]))
+                sw = _Sweep(u, preps[u], FastSampler(rs), re_run_mode)
                 sw.best, sw.n_jobs = best, int(njob_out[u])
                 sw._after_fit()
                 sweeps.append(sw)

@@ -230,3 +230,62 @@ class Sampler:
         b_idx = np.searchsorted(prep.betas, beta, side="left")
         ws = self.init_ws(K, p["max_unif_ws"])
         return a_idx.astype(np.int32), b_idx.astype(np.int32), ws, self.k_arr(K)
+
+
+class FastSampler:
+    """Same draws as :class:`Sampler`, produced by libscape_host.so (include/scape_host.h) on a copy of
+    the RandomState's MT19937 state.  ``rs`` hands the (advanced) RandomState back."""
+
+    def __init__(self, rs):
+        from . import _hostlib
+        self._h, self._lib = _hostlib, _hostlib.load_library()
+        self._rs = rs
+        st = rs.get_state()
+        self._gauss = st[3], st[4]
+        self.state = _hostlib.state_from_numpy(st)
+        self._sp = _hostlib.ptr(self.state, _hostlib.P_u32)
+
+    @property
+    def rs(self):
+        self._rs.set_state(self._h.state_to_numpy(self.state, *self._gauss))
+        return self._rs
+
+    def _python(self):
+        return Sampler(self.rs)
+
+    def _reload(self):
+        self.state[:] = self._h.state_from_numpy(self._rs.get_state())
+
+    def init_ws(self, K, max_unif_ws):
+        w = np.empty(K + 1, dtype=np.float64)
+        if self._lib.scape_host_init_ws(self._sp, K, float(max_unif_ws), self._h.ptr(w, self._h.P_d)):
+            w = self._python().init_ws(K, max_unif_ws)
+            self._reload()
+        return w
+
+    def k_arr(self, K, n=N_ROUND):
+        ka = np.empty(n, dtype=np.int8)
+        if self._lib.scape_host_k_arr(self._sp, K, n, self._h.ptr(ka, self._h.P_i8)):
+            ka = self._python().k_arr(K, n)
+            self._reload()
+        return ka
+
+    def init_job(self, prep, K):
+        h, p = self._h, prep.p
+        c = prep.__dict__.get("_native")
+        if c is None:
+            c = (np.ascontiguousarray(prep.peaks, dtype=np.float64), np.ascontiguousarray(prep.peak_w, dtype=np.float64),
+                 np.ascontiguousarray(prep.theta, dtype=np.float64))
+            prep.__dict__["_native"] = c
+        pk, pw, th = c
+        a, b = np.empty(K, dtype=np.int32), np.empty(K, dtype=np.int32)
+        w, ka = np.empty(K + 1, dtype=np.float64), np.empty(N_ROUND, dtype=np.int8)
+        rc = self._lib.scape_host_init_job(self._sp, h.ptr(pk, h.P_d), h.ptr(pw, h.P_d), len(pk), h.ptr(th, h.P_d),
+                                           len(th), int(prep.L), len(prep.betas), float(5 * p["beta_step"]),
+                                           float(p["max_unif_ws"]), K, N_ROUND, h.ptr(a, h.P_i32), h.ptr(b, h.P_i32),
+                                           h.ptr(w, h.P_d), h.ptr(ka, h.P_i8))
+        if rc:
+            out = self._python().init_job(prep, K)
+            self._reload()
+            return out
+        return a, b, w, ka

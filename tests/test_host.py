@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.scape_hip_abi_version() == 1
 
 
+def test_host_library_exports_every_declared_symbol():
+    from scape_amd import _hostlib
+    hdr = open(os.path.join(ROOT, "include", "scape_host.h")).read()
+    declared = set(re.findall(r"\b(scape_host_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _hostlib.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"libscape_host.so lacks {name}"
+    assert declared == set(_hostlib.SIGNATURES), "ctypes table and header disagree"
+
+
 def test_no_product_import_of_oracle():
     """The product path must never route through the oracle."""
     for root, _dirs, files in os.walk(os.path.join(ROOT, "scape_amd")):
@@ -157,6 +168,59 @@ def test_sampler_consumes_reference_stream():
                     assert np.array_equal(w, f[f"u{i}_call_w0"][c, :K + 1])
                     assert np.array_equal(ka, f[f"u{i}_call_k_arr"][c].astype(int))
                     c += 1
+
+
+def test_native_sampler_equals_numpy_stream():
+    """libscape_host.so draws the numbers numpy's legacy RandomState draws (both init_para branches:
+    K <= #peaks -> choice with p, K > #peaks -> permutation(L)), and leaves the same generator state."""
+    from scape_amd.host import FastSampler, Sampler, prepare_utr
+    from scape_amd.synth import synth_chunk
+    from scape_amd import _hostlib
+    lib = _hostlib.load_library()
+    st = np.zeros(625, dtype=np.uint32)
+    for seed in (0, 1, 12345, 2 ** 32 - 1):
+        lib.scape_host_mt_seed(seed, _hostlib.ptr(st, _hostlib.P_u32))
+        ref = np.random.RandomState(seed)
+        g = ref.get_state()
+        assert np.array_equal(st[:624], g[1]) and st[624] == g[2]
+        assert [lib.scape_host_mt_double(_hostlib.ptr(st, _hostlib.P_u32)) for _ in range(700)] == list(ref.random_sample(700))
+    preps = [prepare_utr(df, g, n_max_apa=12, n_min_apa=1) for g, df in synth_chunk(10, 600, base_seed=5)]
+    f = load_npz("trace_chr17.npz")
+    preps.append(prepare_utr(utr_df(f, 0)[1], gene_info_str="chr17", **trace_params(f)))
+    for u, q in enumerate(preps):
+        r1, r2 = np.random.RandomState(100 + u), np.random.RandomState(100 + u)
+        s1, s2 = Sampler(r1), FastSampler(r2)
+        for K in list(range(14, 0, -1)) + [25]:
+            for _ in range(3):
+                for x, y in zip(s1.init_job(q, K), s2.init_job(q, K)):
+                    assert np.array_equal(x, y) and x.dtype == y.dtype, (u, K)
+            assert np.array_equal(s1.init_ws(K - 1, 0.15), s2.init_ws(K - 1, 0.15))
+            assert np.array_equal(s1.k_arr(K - 1), s2.k_arr(K - 1))
+        g1, g2 = r1.get_state(), s2.rs.get_state()
+        assert np.array_equal(g1[1], g2[1]) and g1[2] == g2[2]
+    # what numpy refuses, the native path declines and numpy then raises as usual
+    q = preps[0]
+    with pytest.raises(ValueError):
+        FastSampler(np.random.RandomState(1)).init_job(q, q.L + len(q.peaks) + 5)
+
+
+def test_native_plan_equals_python_plan():
+    """Engine.plan (scape_host_plan, threaded) == Engine.plan_python (numpy RandomState), table for table,
+    for mixed K ranges and seeds at the 32-bit edge."""
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_chunk
+    chunk = synth_chunk(12, 500, base_seed=9)
+    preps = [prepare_utr(df, g, n_max_apa=(10 if i % 3 else 4), n_min_apa=(1 if i % 2 else 2))
+             for i, (g, df) in enumerate(chunk)]
+    seeds = [(2 ** 32 - 4 + i) % 2 ** 32 for i in range(len(preps))]
+    P1 = Engine.plan_python(preps, seeds)
+    for nt in (1, 3):
+        P2 = Engine.plan(preps, seeds, n_threads=nt)
+        for k in ("ju", "jk", "jf", "a", "b", "w", "ka"):
+            assert np.array_equal(getattr(P1["main"], k), getattr(P2["main"], k)), k
+        for k in ("spans", "states", "prune_w", "prune_ka", "prune_states"):
+            assert np.array_equal(P1[k], P2[k]), k
 
 
 def test_snap_to_grid_ties_go_up(oracle):
