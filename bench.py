@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--kcap", type=int, default=10)
     ap.add_argument("--base-seed", type=int, default=20250225)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-utrs", type=int, default=2048,
+                    help="UTRs of the untimed-by-the-metric end-to-end leg (chunk files -> .res.pkl), 0 = skip")
+    ap.add_argument("--e2e-workers", type=int, default=0, help="prep processes of the end-to-end leg (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
 
@@ -98,12 +101,54 @@ def cpu_baseline(preps, plan, target_s, cores):
                        f"on {cores} threads, {dt:.1f} s wall; 1 UTR on 1 thread = {t1:.2f} s"), [first] + outs
 
 
+def end_to_end(args, pool, dev):
+    """The whole `infer_pa` job as a user runs it, on a bounded sample of the same synthetic stream:
+    prepare_input-style chunk files on disk -> non-executing unpickle -> binning / coverage peaks (process
+    pool) -> restart tables (native sampler) -> GPU -> Parameters -> pkl_output/*.res.pkl.  SURVEY.md 8(d):
+    the rate WITH host pre/post-processing, reported beside `value` (which is the resident-batch rate)."""
+    import shutil
+    import tempfile
+    from scape_amd.apa_core import infer_files
+    from scape_amd.pipeline import synth_chunk_file
+    root = tempfile.mkdtemp(prefix="scape_e2e_")
+    try:
+        os.makedirs(os.path.join(root, "pkl_input"))
+        per_file = 128
+        tasks = [(os.path.join(root, "pkl_input", f"synth.{per_file}.{i}.input.pkl"), 10 ** 6 + i * per_file,
+                  min(per_file, args.e2e_utrs - i * per_file), args.reads, args.kcap, args.base_seed)
+                 for i in range((args.e2e_utrs + per_file - 1) // per_file)]
+        t0 = time.perf_counter()
+        files = list(pool.ex.map(synth_chunk_file, tasks))
+        t_write = time.perf_counter() - t0
+        in_bytes = sum(os.path.getsize(f) for f in files)
+        st = {}
+        t0 = time.perf_counter()
+        written = infer_files(files, root, device=dev, stats=st, rng_mode="per_utr", seed=args.base_seed,
+                              re_run_mode=False, n_max_apa=args.kcap, n_min_apa=1)
+        dt = time.perf_counter() - t0
+        assert len(written) == len(files)
+        out_bytes = sum(os.path.getsize(f) for f in written)
+        return dict(value=args.e2e_utrs / dt, unit="UTRs/s", utrs=args.e2e_utrs, seconds=dt, prep_workers=pool.workers,
+                    chunk_files=len(files), input_bytes=in_bytes, output_bytes=out_bytes,
+                    stages_s={k: round(v, 3) for k, v in st.items() if k.endswith("_s")}, gpu_batches=st.get("n_batch"),
+                    includes="read+unpickle chunk files, binning, coverage peaks, restart sampling, H2D, Phase A/B, "
+                             "EM sweep, BIC selection, prune re-fits, labels, Parameters, pickle write",
+                    synth_write_s=t_write)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    pool = None
+    if world == 1 and args.e2e_utrs > 0:
+        # the end-to-end leg's prep workers: started before this process touches the GPU, idle until then
+        from scape_amd.pipeline import shared_pool
+        pool = shared_pool(args.e2e_workers or None)
     from scape_amd import _lib as _sl
     dev = local_rank % max(1, _sl.device_count())      # one rank per GPU (modulo only matters on a 1-GPU test box)
     if world > 1:
@@ -240,6 +285,9 @@ def main():
                              and np.allclose(fit.ws, ws[j, :K + 1], rtol=1e-4, atol=1e-9))
             out["cpu_baseline"]["parity_sample"] = f"{same}/{len(outs)} sampled UTRs: GPU pA calls identical to the CPU port"
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / cb["value"]
+        if pool is not None:
+            batch.free()
+            out["end_to_end"] = end_to_end(args, pool, dev)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -146,38 +146,49 @@ def _infer_pa(pkl_input_file: str, output_dir: str, **kwargs):
     return infer(pkl_input_file, out_pkl_file, **kwargs)
 
 
-def _load_preps(pkl_input_file, kwargs):
-    pre_para = None
-    if kwargs.get("fixed_run_mode", False):
-        pre_para = next(iter(read_input_chunk(kwargs["pre_para_pkl_file"])))
-    return [prepare_utr(df, gene_info_str=gene, pre_para=pre_para, **kwargs)
-            for gene, df in read_input_chunk(pkl_input_file)]
+def _write_results(output_dir, pkl_input_file, results):
+    out = os.path.join(output_dir, "pkl_output", os.path.basename(pkl_input_file)[:-10] + ".res.pkl")
+    with open(out, "wb") as fh:
+        for r in results:
+            pickle.dump(to_parameters(r), fh)
+    return out
 
 
-def infer_files(files, output_dir, device=None, files_in_flight=32, **kwargs):
-    """Several chunk files on one GPU.  Each file keeps the reference's own random stream
-    (np.random.seed(1) per file, apa_core.py:125) and UTR order, so every <stem>.res.pkl equals what
-    `scape infer_pa` writes for that file; the files only share the GPU launches."""
+def infer_files(files, output_dir, device=None, files_in_flight=32, workers=None, stats=None, **kwargs):
+    """Several chunk files on one GPU; chunk reading / binning runs in a process pool beside the GPU.
+
+    rng_mode 'reference' (default): each file keeps the reference's own random stream (np.random.seed(1)
+    per file, apa_core.py:125) and UTR order, so every <stem>.res.pkl equals what `scape infer_pa` writes
+    for that file; the files only share the GPU launches (Engine.run_streams).
+    rng_mode 'per_utr': UTR j of a file draws from RandomState(seed + j); files stream through
+    scape_amd.pipeline (prep workers -> native planner -> GPU -> writer), the throughput mode."""
     from .engine import Engine
+    from .pipeline import prep_chunk_file, run_pipeline, shared_pool
     os.makedirs(os.path.join(output_dir, "pkl_output"), exist_ok=True)
-    engine = Engine(device=device)
+    seed, re_run = int(kwargs.get("seed", 1)), bool(kwargs.get("re_run_mode", True))
+    tasks = [(f, kwargs) for f in files]
     written = []
-    for i in range(0, len(files), files_in_flight):
-        group = files[i:i + files_in_flight]
-        streams = [(_load_preps(f, kwargs), int(kwargs.get("seed", 1))) for f in group]
-        per_file = engine.run_streams(streams, re_run_mode=bool(kwargs.get("re_run_mode", True)))
-        for f, results in zip(group, per_file):
-            out = os.path.join(output_dir, "pkl_output", os.path.basename(f)[:-10] + ".res.pkl")
-            with open(out, "wb") as fh:
-                for r in results:
-                    pickle.dump(to_parameters(r), fh)
-            written.append(out)
+    pool = shared_pool(workers)                        # before this function initialises the GPU
+    if kwargs.get("rng_mode", "reference") == "per_utr":
+        run_pipeline(tasks, prep_chunk_file, lambda ti, res: written.append(_write_results(output_dir, files[ti], res)),
+                     lambda: Engine(device=device, mem_fraction=0.35), pool, seed=seed, re_run_mode=re_run,
+                     stats=stats)             # two engines share the device (pipeline.run_pipeline)
+        return written
+    engine = Engine(device=device)
+    groups = [tasks[i:i + files_in_flight] for i in range(0, len(tasks), files_in_flight)]
+    pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[0]] if groups else []
+    for gi, group in enumerate(groups):
+        streams = [(fu.result(), seed) for fu in pending]
+        pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[gi + 1]] if gi + 1 < len(groups) else []
+        per_file = engine.run_streams(streams, re_run_mode=re_run)
+        for (f, _kw), results in zip(group, per_file):
+            written.append(_write_results(output_dir, f, results))
     return written
 
 
-def _infer_files_worker(rank, files, output_dir, kwargs):
+def _infer_files_worker(rank, files, output_dir, kwargs, workers):
     os.environ["LOCAL_RANK"] = str(rank)
-    infer_files(files, output_dir, device=rank, **kwargs)
+    infer_files(files, output_dir, device=rank, workers=workers, **kwargs)
 
 
 def infer_all(output_dir, gpus=1, **kwargs):
@@ -197,7 +208,9 @@ def infer_all(output_dir, gpus=1, **kwargs):
         infer_files(files, output_dir, device=kwargs.pop("device", None), **kwargs)
         return files
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_infer_files_worker, args=(r, [files[i] for i in shards[r]], output_dir, kwargs))
+    workers = max(1, (os.cpu_count() or 1) // gpus - 2)          # prep processes per GPU worker
+    procs = [ctx.Process(target=_infer_files_worker,
+                         args=(r, [files[i] for i in shards[r]], output_dir, kwargs, workers))
              for r in range(gpus) if shards[r]]
     for p in procs:
         p.start()

@@ -307,6 +307,10 @@ class Engine:
         npad = (q.N + 15) // 16 * 16
         return 8 * npad * q.T * (len(q.betas) + 2) + 48 * q.N
 
+    def load(self, preps):
+        """Upload one wave of prepared UTRs (scape_hip_batch_load)."""
+        return HipBatch(self.ctx, preps)
+
     def waves(self, preps):
         """Split into waves whose tensors fit the device (at most 65535 UTRs each)."""
         budget = self._budget()

@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: multi-second CPU test")
 
 
+def pytest_sessionstart(session):
+    """GPU runs: bring the prep-worker pool up before any test initialises the GPU, so its fork server
+    is born without a HIP context (scape_amd/pipeline.py)."""
+    m = session.config.getoption("-m") or ""
+    if "gpu" in m and "not gpu" not in m:
+        from scape_amd.pipeline import shared_pool
+        shared_pool(4)
+
+
 def load_npz(name):
     return np.load(os.path.join(GOLDEN, name))
 

@@ -465,6 +465,60 @@ def test_infer_pa_all_equals_per_file_runs(tmp_path):
             assert np.array_equal(a.lb_arr, b.lb_arr)
 
 
+def test_pipelined_per_utr_mode_equals_engine_run(tmp_path, oracle):
+    """rng_mode='per_utr' through the host pipeline (prep processes -> native planner -> GPU thread ->
+    writer, batches that straddle file boundaries) writes exactly what Engine.run gives for each file on
+    its own with seeds seed + j, and those equal the oracle run from the same per-UTR RandomState."""
+    from scape_amd.apa_core import infer_files, read_input_chunk, to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_chunk
+    out = tmp_path / "out"
+    (out / "pkl_input").mkdir(parents=True)
+    kw = dict(n_max_apa=4, n_min_apa=1, re_run_mode=True)
+    files = []
+    for fi, n in enumerate((5, 0, 7, 3)):
+        f = out / "pkl_input" / f"p{fi}.100.4.{fi + 1}.input.pkl"
+        with open(f, "wb") as fh:
+            for g, df in synth_chunk(n, 300 + 40 * fi, k_cap=4, base_seed=300 + 10 * fi, pa_rate=0.04):
+                pickle.dump((g, df), fh)
+        files.append(str(f))
+    import scape_amd.pipeline as pl
+    orig = pl.run_pipeline
+    try:
+        pl.run_pipeline = lambda *a, **k: orig(*a, **{**k, "batch_utrs": 4})      # force file-straddling batches
+        stats = {}
+        written = infer_files(files, str(out), rng_mode="per_utr", seed=7, stats=stats, **kw)
+    finally:
+        pl.run_pipeline = orig
+    assert [os.path.basename(w) for w in written] == [os.path.basename(f)[:-10] + ".res.pkl" for f in files]
+    assert stats["n_utr"] == 15 and stats["n_batch"] == 4
+    eng = Engine()
+    for f, w in zip(files, written):
+        utrs = list(read_input_chunk(f))
+        got = []
+        with open(w, "rb") as fh:
+            while True:
+                try:
+                    got.append(pickle.load(fh))
+                except EOFError:
+                    break
+        assert len(got) == len(utrs)
+        if not utrs:
+            continue
+        preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in utrs]
+        want = [to_parameters(r) for r in eng.run(preps, rng_mode="per_utr", seed=7, re_run_mode=True)]
+        for j, (a, b, (g, df)) in enumerate(zip(got, want, utrs)):
+            assert a.gene_info_str == b.gene_info_str == g and a.K == b.K
+            assert np.array_equal(a.alpha_arr, b.alpha_arr) and np.array_equal(a.beta_arr, b.beta_arr)
+            assert np.array_equal(a.ws, b.ws) and a.bic == b.bic and np.array_equal(a.label_arr, b.label_arr)
+            np.random.seed(7 + j)                                     # the oracle draws from the global stream
+            ref, _m = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, **kw)
+            assert a.K == ref.K and np.array_equal(a.alpha_arr, ref.alpha_arr) and np.array_equal(a.beta_arr, ref.beta_arr)
+            assert np.allclose(a.ws, ref.ws, rtol=1e-9, atol=1e-13) and a.bic == pytest.approx(ref.bic, rel=1e-10)
+            assert np.array_equal(a.label_arr, ref.label_arr)
+
+
 @pytest.mark.parametrize("reads,kcap,n", [(10000, 10, 2), (5000, 12, 2)])
 def test_deep_pileup_shapes_vs_oracle(oracle, reads, kcap, n):
     """BASELINE configs #4 (10k reads, K<=10) and #5 (5k reads, K=1..12) shapes, two UTRs each, every job
