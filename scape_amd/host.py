@@ -68,7 +68,10 @@ def kernel_smooth(y, bw):
     if ny > 2 * half:
         win = sliding_window_view(y, 2 * half + 1)          # rows are y[i-half : i+half+1]
         out[half:ny - half] = np.sum(win * w, axis=1) / np.sum(w)
-    for i in list(range(min(half, ny))) + list(range(max(ny - half, half), ny)):
+    edge = list(range(min(half, ny))) + list(range(max(ny - half, half), ny))
+    if ny > 4 * half and not y[:2 * half].any() and not y[ny - 2 * half:].any():
+        edge = []                   # zero-padded profile (coverage_profile): every edge window sums to +0.0
+    for i in edge:
         a, b = max(i - half, 0), min(i + half, ny - 1)
         ww = w[a - (i - half):b - (i - half) + 1]
         out[i] = np.sum(ww * y[a:b + 1]) / np.sum(ww)
