@@ -7,7 +7,8 @@
  *     owns device memory behind an opaque context (one context per GPU);
  *   - every entry point returns 0 on success, non-zero on error;
  *     scape_hip_last_error() returns the message of the calling thread's last error;
- *   - calls on one context are not re-entrant (one host thread per context);
+ *   - calls on one context are not re-entrant (one host thread per context): a call that arrives while
+ *     another is in flight on the same context fails with an error; use one context per thread;
  *   - all floating point is IEEE f64; SCAPE_SENT is the reference's finite "-inf"
  *     (np.finfo('f').min, reference src/scape/taichi_core.py:8, apa_core.py:428).
  *

@@ -171,7 +171,7 @@ def infer_files(files, output_dir, device=None, files_in_flight=32, workers=None
     pool = shared_pool(workers)                        # before this function initialises the GPU
     if kwargs.get("rng_mode", "reference") == "per_utr":
         run_pipeline(tasks, prep_chunk_file, lambda ti, res: written.append(_write_results(output_dir, files[ti], res)),
-                     lambda: Engine(device=device, mem_fraction=0.35), pool, seed=seed, re_run_mode=re_run,
+                     lambda: Engine(device=device, mem_fraction=0.35, own_context=True), pool, seed=seed, re_run_mode=re_run,
                      stats=stats)             # two engines share the device (pipeline.run_pipeline)
         return written
     engine = Engine(device=device)

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -811,6 +812,7 @@ struct EventPair {
 
 struct scape_hip_ctx {
     int device = 0;
+    std::atomic<bool> busy{false};   // a handle serves one host thread at a time (scape_hip.h)
     hipStream_t stream = nullptr, stream2 = nullptr;
     char name[256] = {0};
     DevParams prm;
@@ -867,6 +869,22 @@ static int set_device(scape_hip_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     return 0;
 }
+
+// Calls on one handle are not re-entrant: a second host thread entering while a call is in flight gets an
+// error instead of racing on the handle's device buffers.
+struct BusyGuard {
+    scape_hip_ctx *c;
+    bool ok;
+    explicit BusyGuard(scape_hip_ctx *ctx) : c(ctx), ok(ctx && !ctx->busy.exchange(true)) {}
+    ~BusyGuard() { if (ok) c->busy.store(false); }
+};
+#define CTX_GUARD(c)                                                                                      \
+    if (!(c)) return fail("ctx is NULL");                                                                 \
+    BusyGuard busy_guard_(c);                                                                             \
+    if (!busy_guard_.ok) return fail("handle is in use by another host thread (calls on a handle are not re-entrant)")
+#define CTX_ENTER(c)                                                                                      \
+    CTX_GUARD(c);                                                                                         \
+    if (set_device(c)) return 1
 
 static void fill_params(DevParams &d, double mu_f, double sigma_f, double max_unif_ws, int B,
                         const double *betas, int S, const double *s, const double *pmf, int nround) {
@@ -1119,7 +1137,7 @@ int scape_hip_device_name(scape_hip_ctx *c, char *buf, int buflen) {
 
 int scape_hip_batch_free(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     DevBuf *all[] = {&c->d_tile_nend, &c->d_x, &c->d_l, &c->d_r, &c->d_pa, &c->d_cnt, &c->d_theta, &c->d_desc, &c->d_loglist,
                      &c->d_AT, &c->d_V, &c->d_M, &c->j_utr, &c->j_K, &c->j_fixed, &c->j_a, &c->j_b, &c->j_ws,
                      &c->j_karr, &c->j_ao, &c->j_bo, &c->j_wso, &c->j_bic, &c->j_nlb, &c->j_lb, &c->l_utr,
@@ -1181,6 +1199,7 @@ static int op_finish(scape_hip_ctx *c, int n, double **dev, int n_in, double *do
 
 int scape_hip_loglik_xlr_t_pa(scape_hip_ctx *c, const double *x, const double *l, const double *pa,
                               int32_t n, double theta, double sigma_f, double *out) {
+    CTX_GUARD(c);
     const double *in[3] = {x, l, pa};
     double *dev[3] = {nullptr, nullptr, nullptr}, *dout = nullptr;
     if (op_common(c, n, in, 3, dev, &dout)) return 1;
@@ -1191,6 +1210,7 @@ int scape_hip_loglik_xlr_t_pa(scape_hip_ctx *c, const double *x, const double *l
 int scape_hip_loglik_xlr_t_r_known(scape_hip_ctx *c, const double *x, const double *l, const double *r,
                                    int32_t n, const double *s_dis, const double *pmf_s, int32_t n_s,
                                    double theta, double mu_f, double sigma_f, double *out) {
+    CTX_GUARD(c);
     if (n_s < 1 || n_s > SCAPE_MAX_S) return fail("n_s out of range");
     DevParams P;
     fill_params(P, mu_f, sigma_f, 0, 0, nullptr, n_s, s_dis, pmf_s, 0);
@@ -1204,6 +1224,7 @@ int scape_hip_loglik_xlr_t_r_known(scape_hip_ctx *c, const double *x, const doub
 int scape_hip_loglik_xlr_t_r_unknown(scape_hip_ctx *c, const double *x, const double *l, const double *r,
                                      int32_t n, const double *s_dis, const double *pmf_s, int32_t n_s,
                                      double theta, double mu_f, double sigma_f, double *out) {
+    CTX_GUARD(c);
     (void)r;
     if (n_s < 1 || n_s > SCAPE_MAX_S) return fail("n_s out of range");
     DevParams P;
@@ -1222,7 +1243,7 @@ int scape_hip_get_loglik_marginal_tensor(scape_hip_ctx *c, const double *all_the
     if (T < 1 || N < 1) return fail("empty theta grid or no fragments");
     if (B < 1 || B > SCAPE_MAX_BETA) return fail("n_beta out of range");
     if (!all_theta || !betas || !A || !out) return fail("NULL argument");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     for (int i = 1; i < T; ++i)
         if (!(all_theta[i] >= all_theta[i - 1])) return fail("all_theta must be ascending");
     DevParams P;
@@ -1285,7 +1306,7 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
     if (p->nround < 1 || p->nround > 127) return fail("nround out of range");
     if (!bin_off || !x || !l || !r || !pa || !cnt || !theta_off || !all_theta || !utr_L || !min_theta || !unif_ll)
         return fail("NULL array argument");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     c->loaded = c->built = false;
     fill_params(c->prm, p->mu_f, p->sigma_f, p->max_unif_ws, p->n_beta, p->betas, p->n_s, p->s_dis, p->pmf_s, p->nround);
     double bmax = p->betas[0];
@@ -1360,7 +1381,7 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
 
 int scape_hip_batch_bytes(scape_hip_ctx *c, int64_t *bytes_batch, int64_t *bytes_free, int64_t *bytes_total) {
     if (!c) return fail("ctx is NULL");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     size_t f = 0, t = 0;
     HIPCHK(hipMemGetInfo(&f, &t));
     if (bytes_batch) *bytes_batch = c->loaded ? (int64_t)((2 * c->at_total + c->m_total) * 8 + c->n_bins * 40) : 0;
@@ -1372,7 +1393,7 @@ int scape_hip_batch_bytes(scape_hip_ctx *c, int64_t *bytes_batch, int64_t *bytes
 int scape_hip_batch_build(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
     if (!c->loaded) return fail("no batch loaded");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     dim3 grid((c->Np_max + 255) / 256, c->T_max, c->n_utr);
     if (ev_begin(c, 0)) return 1;
     hipLaunchKernelGGL(k_phase_a, grid, dim3(256), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm, c->d_x.as<double>(),
@@ -1406,7 +1427,7 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     if (!job_utr || !job_K || !job_fixed || !alpha_idx || !beta_idx || !ws || !k_arr || !alpha_idx_out ||
         !beta_idx_out || !ws_out || !bic_out || !n_lb_out || !lb_out)
         return fail("NULL array argument");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     const int nround = c->prm.nround, B = c->prm.B;
     // host-side validation: every index a kernel dereferences is checked here
     for (int j = 0; j < n_jobs; ++j) {
@@ -1480,7 +1501,7 @@ int scape_hip_batch_labels(scape_hip_ctx *c, int32_t n_sel, int32_t kmax, const 
     if (n_sel < 1) return fail("n_sel < 1");
     if (kmax < 1 || kmax > SCAPE_MAX_K) return fail("kmax out of range");
     if (!sel_utr || !sel_K || !alpha_idx || !beta_idx || !ws || !labels_out) return fail("NULL array argument");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     const int B = c->prm.B;
     for (int j = 0; j < n_sel; ++j) {
         const int u = sel_utr[j], K = sel_K[j];
@@ -1538,7 +1559,7 @@ int scape_hip_batch_fetch_loglik(scape_hip_ctx *c, int32_t utr, double *A_out) {
     if (!c || !A_out) return fail("NULL argument");
     if (!c->built) return fail("batch_build has not run");
     if (utr < 0 || utr >= c->n_utr) return fail("bad UTR index");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     const UtrDesc &d = c->h_desc[utr];
     std::vector<double> at((size_t)d.T * d.Np);
     HIPCHK(hipMemcpy(at.data(), c->d_AT.as<double>() + d.at_off, at.size() * 8, hipMemcpyDeviceToHost));
@@ -1551,7 +1572,7 @@ int scape_hip_batch_fetch_tensor(scape_hip_ctx *c, int32_t utr, double *M_out) {
     if (!c || !M_out) return fail("NULL argument");
     if (!c->built) return fail("batch_build has not run");
     if (utr < 0 || utr >= c->n_utr) return fail("bad UTR index");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     const UtrDesc &d = c->h_desc[utr];
     HIPCHK(hipMemcpy2D(M_out, (size_t)d.N * 8, c->d_M.as<double>() + d.m_off, (size_t)d.Np * 8, (size_t)d.N * 8,
                        (size_t)d.T * c->prm.B, hipMemcpyDeviceToHost));
@@ -1560,7 +1581,7 @@ int scape_hip_batch_fetch_tensor(scape_hip_ctx *c, int32_t utr, double *M_out) {
 
 int scape_hip_timing_reset(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     if (ev_collect(c)) return 1;
     for (int w = 0; w < 6; ++w) {
         c->ms_acc[w] = 0;
@@ -1572,7 +1593,7 @@ int scape_hip_timing_reset(scape_hip_ctx *c) {
 int scape_hip_timing_get(scape_hip_ctx *c, int32_t which, double *ms_total, int32_t *n_launches) {
     if (!c) return fail("ctx is NULL");
     if (which < 0 || which > 5) return fail("which out of range");
-    if (set_device(c)) return 1;
+    CTX_ENTER(c);
     if (ev_collect(c)) return 1;
     if (ms_total) *ms_total = c->ms_acc[which];
     if (n_launches) *n_launches = c->n_acc[which];

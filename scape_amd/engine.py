@@ -292,8 +292,15 @@ class _Sweep:
 class Engine:
     """infer_pa for lists of UTRs on one GPU."""
 
-    def __init__(self, device=None, mem_fraction=0.7):
-        self.ctx = _lib.default_context(device)
+    def __init__(self, device=None, mem_fraction=0.7, own_context=False):
+        """own_context: create a private library handle (own HIP stream and device buffers) instead of the
+        process-wide one per device - required for engines that run on different host threads."""
+        if own_context:
+            if device is None:
+                device = _lib.default_context(None).device
+            self.ctx = _lib.Context(device)
+        else:
+            self.ctx = _lib.default_context(device)
         self.mem_fraction = mem_fraction
 
     def _budget(self):

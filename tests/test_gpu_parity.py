@@ -344,6 +344,44 @@ def test_c_abi_error_paths(hip_ctx):
     batch.free()
 
 
+def test_handle_rejects_concurrent_calls():
+    """Calls on one handle are not re-entrant (scape_hip.h): a second host thread that enters while a
+    call is in flight gets an error, the call in flight is unharmed; a private handle per thread works."""
+    import ctypes
+    import threading
+    from scape_amd import _lib
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_chunk
+    preps = [prepare_utr(df, gene_info_str=g, n_max_apa=6) for g, df in synth_chunk(24, 1500, k_cap=6, base_seed=77)]
+    seeds = list(range(24))
+    want = Engine().run(preps, rng_mode="per_utr", seeds=seeds, re_run_mode=False)
+    eng = Engine(own_context=True)
+    assert eng.ctx is not _lib.default_context(None)
+    got, errs, done = [], [], threading.Event()
+
+    def work():
+        try:
+            for _ in range(3):
+                got.append(eng.run(preps, rng_mode="per_utr", seeds=seeds, re_run_mode=False))
+        finally:
+            done.set()
+    th = threading.Thread(target=work)
+    th.start()
+    a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    while not done.is_set():
+        if eng.ctx.lib.scape_hip_batch_bytes(eng.ctx.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)):
+            errs.append(_lib.last_error())
+    th.join()
+    assert errs and all("in use by another host thread" in e for e in errs)
+    assert len(got) == 3
+    for res in got:
+        for r, w in zip(res, want):
+            assert r.fit.K == w.fit.K and np.array_equal(r.fit.a_idx, w.fit.a_idx) and np.array_equal(r.fit.ws, w.fit.ws)
+            assert np.array_equal(r.labels_bin, w.labels_bin)
+    eng.ctx.close()
+
+
 # ---------------------------------------------------------------- properties at the headline shape
 def test_properties_headline_shape():
     """2k reads x K<=10 (BASELINE config #3 shape), 24 UTRs: determinism and model invariants."""
