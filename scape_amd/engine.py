@@ -18,6 +18,7 @@ RNG modes
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from dataclasses import dataclass, field
 
@@ -302,6 +303,7 @@ class Engine:
         else:
             self.ctx = _lib.default_context(device)
         self.mem_fraction = mem_fraction
+        self.sweep_lock = None       # optional threading.Lock shared by engines on one device (pipeline.py)
 
     def _budget(self):
         fb, tb, bb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
@@ -540,11 +542,14 @@ class Engine:
         selection, prune re-fits, re-run sweeps and labels.  Returns [(Fit, labels_bin, n_jobs)]."""
         from time import perf_counter as _now
         t0 = _now()
-        batch.build()
         pj, spans = plan["main"], plan["spans"]
-        ms0 = batch.timing(2)[0]
-        out = batch.em_packed(pj, reuse_buffers=True)
-        self.last_main_em_ms = batch.timing(2)[0] - ms0          # HIP-event time of the sweep launch
+        # engines that share a device take turns for the long kernels (two EM sweeps at once only slow each
+        # other down); uploads, host-side selection and the short re-fit launches overlap freely
+        with (self.sweep_lock if self.sweep_lock is not None else contextlib.nullcontext()):
+            batch.build()
+            ms0 = batch.timing(2)[0]
+            out = batch.em_packed(pj, reuse_buffers=True)
+            self.last_main_em_ms = batch.timing(2)[0] - ms0          # HIP-event time of the sweep launch
         self.last_main_counters = batch.em_counters()
         t1 = _now()
         ao, bo, wo, bic, nlb, lb = out

@@ -113,6 +113,7 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
     st = stats if stats is not None else {}
     st.update(prep_wait_s=0.0, plan_s=0.0, gpu_s=0.0, gpu_idle_s=0.0, sink_s=0.0, n_utr=0, n_batch=0)
     waiting = [0]                                    # GPU threads blocked on an empty queue
+    sweep_lock = threading.Lock()
     # the GPU threads re-take the GIL after every C-ABI call; with two busy Python threads beside them the
     # default 5 ms switch interval would add up to more than the kernels take
     old_switch = sys.getswitchinterval()
@@ -166,6 +167,7 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
     def gpu_stage():
         try:
             eng = engine_factory()
+            eng.sweep_lock = sweep_lock
             while True:
                 t0 = perf_counter()
                 waiting[0] += 1
