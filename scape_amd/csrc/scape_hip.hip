@@ -849,10 +849,14 @@ static int ev_end(scape_hip_ctx *c, int which) {
 }
 static int ev_collect(scape_hip_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
+    const bool trace = getenv("SCAPE_HIP_ROUND_TRACE") != nullptr;   // per-launch durations on stderr
     for (int w = 0; w < 6; ++w) {
+        int i = 0;
         for (auto &e : c->ev[w]) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            if (trace && w >= 4) fprintf(stderr, "[trace] kind %d launch %d %.4f ms\n", w, i, ms);
+            ++i;
             c->ms_acc[w] += ms;
             c->n_acc[w] += 1;
             (void)hipEventDestroy(e.a);
