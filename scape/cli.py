@@ -1,7 +1,9 @@
-"""click group exposing ``infer_pa`` (reference cli.py:7-31 registers six commands)."""
+"""click group exposing ``infer_pa`` and its consumer ``merge_pa`` (reference cli.py:7-31 registers six
+commands; the other four are outside this build's scope)."""
 import click
 
 from scape_amd.apa_core import infer_pa, infer_pa_all
+from scape_amd.junction_handler import merge_pa
 
 
 @click.group()
@@ -18,3 +20,4 @@ def display_paper_info():
 
 cli.add_command(infer_pa)
 cli.add_command(infer_pa_all)
+cli.add_command(merge_pa)

@@ -22,7 +22,13 @@ Two kinds of data are written, both plain ``.npz`` (numeric arrays + strings):
 Nothing is written under /root/reference (``sys.dont_write_bytecode``), and the
 reference never travels: only the ``.npz`` files do.
 
-Usage: python tests/golden/make_golden.py [fixtures|traces|synth|all] [names...]
+3. ``fixture_merge.npz`` / ``trace_merge_syn.npz`` - the same two kinds for ``merge_pa``
+   (reference ``src/scape/junction_handler.py``): the example directories' inputs, ``.res.pkl`` records
+   and committed ``res.gene.pkl`` / ``res.utr.pkl`` transcribed with the symbolic reader; and the outputs
+   of the reference's own ``proc_junction_{pos,neg}_pa`` run here on randomly generated genes
+   (several UTR records per gene, junction reads that trigger merges, tied positions, empty sites).
+
+Usage: python tests/golden/make_golden.py [fixtures|traces|synth|fixed|merge|all] [names...]
 """
 from __future__ import annotations
 
@@ -356,6 +362,179 @@ def write_fixed():
     run_reference_file("synF", utrs, p, seed=3, keep_full_tensor=True, pre_para=pre)
 
 
+# ---------------------------------------------------------------- merge_pa (junction_handler.py)
+MERGE_DIRS = {"toy": ("examples/toy-example", ["example.100.1.1"]),
+              "scz": ("examples/SCZ-nowa-scape", ["chr17_merge.100.1.1", "chr19_merge.100.1.1"])}
+PARA_FIELDS = ("alpha_arr", "beta_arr", "label_arr", "cb_id_arr", "readID_arr")
+
+
+def _put_para(d, pre, p, with_ws=False):
+    d[pre + "gene_info_str"] = np.array(p.gene_info_str)
+    d[pre + "K"] = np.array(int(p.K))
+    for f in PARA_FIELDS:
+        d[pre + f] = np.asarray(getattr(p, f))
+    if with_ws:
+        d[pre + "ws"] = np.asarray(p.ws)
+        d[pre + "L"] = np.array(int(p.L))
+        d[pre + "title"] = np.array(p.title)
+
+
+def _put_input(d, pre, df):
+    for c in ("read_id", "junction", "seg1_en", "seg2_en"):
+        d[pre + "in_" + c] = df[c].to_numpy()
+
+
+def write_merge_fixtures():
+    """The example directories as merge_pa sees them + the committed res.gene.pkl / res.utr.pkl."""
+    d = {"names": np.array(list(MERGE_DIRS))}
+    for name, (sub, stems) in MERGE_DIRS.items():
+        recs = []
+        for stem in stems:
+            ins = {g: df for g, df in load_all(open(os.path.join(REF, sub, "pkl_input", stem + ".input.pkl"), "rb").read())}
+            for p in load_all(open(os.path.join(REF, sub, "pkl_output", stem + ".res.pkl"), "rb").read()):
+                recs.append((p, ins[p.gene_info_str]))
+        d[f"{name}_n_rec"] = np.array(len(recs))
+        for j, (p, df) in enumerate(recs):
+            _put_para(d, f"{name}_r{j}_", p)
+            _put_input(d, f"{name}_r{j}_", df)
+        for mode, fn in (("gene", "res.gene.pkl"), ("utr", "res.utr.pkl")):
+            gold = load_all(open(os.path.join(REF, sub, fn), "rb").read())
+            d[f"{name}_{mode}_n_gold"] = np.array(len(gold))
+            for j, p in enumerate(gold):
+                _put_para(d, f"{name}_{mode}_g{j}_", p, with_ws=True)
+    path = os.path.join(HERE, "fixture_merge.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path))
+
+
+def _fuzz_gene(rng, gi):
+    """One random gene: [(gene_info_str, input columns, result fields)] - positions, junction reads and read
+    shares chosen so that merges, chains of merges, dropped sites, tied positions and empty sites all occur."""
+    strand = "+" if rng.random() < 0.5 else "-"
+    chrom, gene = f"chr{1 + gi % 22}", f"G{gi:05d}"
+    n_rec = int(rng.choice([1, 1, 2, 3]))
+    base = int(rng.integers(10 ** 5, 10 ** 6))
+    recs, sites = [], []                                     # sites: absolute positions seen so far
+    for r in range(n_rec):
+        st = base + int(rng.integers(0, 3000)) * (r > 0) + 2500 * r * int(rng.random() < 0.6)
+        en = st + int(rng.integers(1500, 4000))
+        K = int(rng.choice([0, 1, 2, 3, 4], p=[0.06, 0.3, 0.3, 0.22, 0.12]))
+        if r == n_rec - 1 and not any(k for _g, _c, k in [(a, b, c["K"]) for a, b, c in recs]) and K == 0:
+            K = 1                                            # the reference cannot process a gene without any site
+        alpha = np.sort(rng.choice(np.arange(60, en - st - 60), size=K, replace=False)).astype(np.int64)
+        if K and sites and rng.random() < 0.3:               # tie: put one site on an absolute position already used
+            tgt = int(rng.choice(sites))
+            a = (tgt - st) if strand == "+" else (en - tgt + 1)
+            if 0 < a < en - st and a not in alpha:
+                alpha[int(rng.integers(K))] = a
+                alpha = np.sort(alpha)
+        loc = (st + alpha) if strand == "+" else (en - alpha + 1)
+        sites.extend(int(v) for v in loc)
+        beta = rng.choice(np.arange(5, 70, 5), size=K).astype(np.float64)
+        n = int(rng.integers(30, 180))
+        w = rng.dirichlet(np.full(K + 1, 0.6)) if K else np.ones(1)
+        if K > 1 and rng.random() < 0.25:
+            w[int(rng.integers(K))] = 0.0                     # a site nobody is assigned to
+            w = w / w.sum()
+        label = rng.choice(K + 1, size=n, p=w).astype(np.int64)
+        read_id = rng.permutation(10 ** 6)[:n].astype(np.int64) + 7
+        cb_id = rng.integers(0, 5000, size=n).astype(np.int64)
+        junction = (rng.random(n) < 0.08).astype(np.int64)
+        seg1 = np.full(n, np.nan)
+        seg2 = np.full(n, np.nan)
+        recs.append([f"{chrom}:{gene}:{r + 1}:{st}-{en}:{strand}",
+                     dict(read_id=read_id, junction=junction, seg1_en=seg1, seg2_en=seg2, cb_id=cb_id),
+                     dict(K=K, alpha_arr=alpha, beta_arr=beta, label_arr=label, cb_id_arr=cb_id, readID_arr=read_id,
+                          loc=loc)])
+    all_loc = np.sort(np.array(sites, dtype=np.int64))
+    for _g, cols, res in recs:                               # junction reads: segment ends near real sites
+        n, K = len(cols["read_id"]), res["K"]
+        for k in range(K):
+            mine = np.nonzero(res["label_arr"] == k)[0]
+            if len(mine) and rng.random() < 0.45:            # a junction-dominated site
+                take = mine[rng.random(len(mine)) < rng.uniform(0.35, 0.95)]
+                cols["junction"][take] = 1
+        jr = np.nonzero(cols["junction"] == 1)[0]
+        for i in jr:
+            k = int(res["label_arr"][i])
+            own = int(res["loc"][k]) if k < K else int(rng.choice(all_loc))
+            far = int(rng.choice(all_loc)) if rng.random() < 0.8 else own
+            d1, d2 = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))
+            if strand == "+":                                # own site lies 3' of segment 2's end
+                cols["seg2_en"][i], cols["seg1_en"][i] = own - abs(d1), far - abs(d2) * int(rng.random() < 0.9)
+            else:
+                cols["seg1_en"][i], cols["seg2_en"][i] = own + abs(d1), far + abs(d2) * int(rng.random() < 0.9)
+        if len(jr) and rng.random() < 0.05:
+            cols["seg1_en"][jr[0]] = np.nan
+    return recs
+
+
+def write_merge_trace(n_genes=150, seed=20250226):
+    """Reference proc_junction_{pos,neg}_pa on random genes, utr_merge True and False."""
+    import signal
+
+    import pandas as pd
+    load_reference()
+    import importlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        jh = importlib.import_module("scape.junction_handler")
+    RefPara = sys.modules["scape.apa_core"].Parameters
+    rng = np.random.default_rng(seed)
+    d, n_case, skipped, t_ref = {}, 0, 0, 0.0
+
+    def on_alarm(*_a):
+        raise TimeoutError
+
+    signal.signal(signal.SIGALRM, on_alarm)
+    for gi in range(n_genes):
+        recs = _fuzz_gene(rng, gi)
+        groups = [("gene", recs[0][0].split(":")[1], recs)]
+        groups += [("utr", ":".join(g.split(":")[1:3]), [rec]) for rec in recs for g in [rec[0]] if rec[2]["K"] > 0]
+        for mode, key, grp in groups:
+            ins, res = {}, {}
+            for g, cols, r in grp:
+                n = len(cols["read_id"])
+                perm = rng.permutation(n)                    # input rows in another order than the result's reads
+                ins[g] = pd.DataFrame({"x": np.zeros(n, np.int64), "l": np.full(n, 50), "r": np.full(n, np.nan),
+                                       "pa": np.full(n, np.nan), "cb_id": cols["cb_id"][perm],
+                                       "read_id": cols["read_id"][perm], "junction": cols["junction"][perm],
+                                       "seg1_en": cols["seg1_en"][perm], "seg2_en": cols["seg2_en"][perm]})
+                p = RefPara(title="Final Result", alpha_arr=r["alpha_arr"].copy(), beta_arr=r["beta_arr"].copy(),
+                            ws=np.full(r["K"] + 1, 1.0 / (r["K"] + 1)), L=int(g.split(":")[3].split("-")[1]) - int(g.split(":")[3].split("-")[0]),
+                            cb_id_arr=r["cb_id_arr"].copy(), readID_arr=r["readID_arr"].copy())
+                p.label_arr, p.gene_info_str = r["label_arr"].copy(), g
+                res[g] = p
+            fn = jh.proc_junction_pos_pa if list(res)[0][-1:] == "+" else jh.proc_junction_neg_pa
+            signal.alarm(20)
+            t_ref0 = time.perf_counter()
+            try:
+                with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                    import warnings
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        out, junc, change = fn(ins, res, key, 0.4, 0.05)
+            except TimeoutError:
+                skipped += 1
+                continue
+            finally:
+                signal.alarm(0)
+            t_ref += time.perf_counter() - t_ref0
+            pre = f"c{n_case}_"
+            d[pre + "key"], d[pre + "n_rec"] = np.array(key), np.array(len(grp))
+            d[pre + "junc"], d[pre + "change"] = np.array(junc), np.array(change)
+            for j, (g, _cols, r) in enumerate(grp):
+                rp = res[g]
+                _put_para(d, f"{pre}r{j}_", rp)
+                _put_input(d, f"{pre}r{j}_", ins[g])
+            _put_para(d, pre + "out_", out, with_ws=True)
+            n_case += 1
+    d["n_case"] = np.array(n_case)
+    d["ref_seconds"] = np.array(t_ref)                   # the reference's own time for these cases, this container
+    path = os.path.join(HERE, "trace_merge_syn.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path), "cases", n_case, "skipped (reference did not finish)", skipped)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     names = sys.argv[2:] or list(FIXTURE_FILES)
@@ -365,5 +544,8 @@ if __name__ == "__main__":
         write_synth()
     if what in ("fixed", "all"):
         write_fixed()
+    if what in ("merge", "all"):
+        write_merge_fixtures()
+        write_merge_trace()
     if what in ("traces", "all"):
         write_traces(names)
