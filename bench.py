@@ -128,7 +128,21 @@ def end_to_end(args, pool, dev):
         dt = time.perf_counter() - t0
         assert len(written) == len(files)
         out_bytes = sum(os.path.getsize(f) for f in written)
+        # the same job again from pre-binned columnar chunks (scape prebin, scape_amd/binned.py)
+        from scape_amd.pipeline import prebin_chunk_file
+        t0 = time.perf_counter()
+        bfiles = list(pool.ex.map(prebin_chunk_file, files))
+        t_prebin = time.perf_counter() - t0
+        st2 = {}
+        t0 = time.perf_counter()
+        infer_files(files, root, device=dev, stats=st2, rng_mode="per_utr", seed=args.base_seed,
+                    re_run_mode=False, n_max_apa=args.kcap, n_min_apa=1)
+        dt2 = time.perf_counter() - t0
+        prebinned = dict(value=args.e2e_utrs / dt2, seconds=dt2, prebin_s=t_prebin,
+                         binned_bytes=sum(os.path.getsize(f) for f in bfiles),
+                         stages_s={k: round(v, 3) for k, v in st2.items() if k.endswith("_s")})
         return dict(value=args.e2e_utrs / dt, unit="UTRs/s", utrs=args.e2e_utrs, seconds=dt, prep_workers=pool.workers,
+                    from_prebinned_chunks=prebinned,
                     chunk_files=len(files), input_bytes=in_bytes, output_bytes=out_bytes,
                     stages_s={k: round(v, 3) for k, v in st.items() if k.endswith("_s")}, gpu_batches=st.get("n_batch"),
                     includes="read+unpickle chunk files, binning, coverage peaks, restart sampling, H2D, Phase A/B, "

@@ -2,7 +2,7 @@
 commands; the other four are outside this build's scope)."""
 import click
 
-from scape_amd.apa_core import infer_pa, infer_pa_all
+from scape_amd.apa_core import infer_pa, infer_pa_all, prebin
 from scape_amd.junction_handler import merge_pa
 
 
@@ -21,3 +21,4 @@ def display_paper_info():
 cli.add_command(infer_pa)
 cli.add_command(infer_pa_all)
 cli.add_command(merge_pa)
+cli.add_command(prebin)

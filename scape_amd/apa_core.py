@@ -104,18 +104,29 @@ def read_input_chunk(path):
         yield from safe_pickle.iter_pickles(path)
 
 
-def infer(pickle_input_file, pickle_output_file, **kwargs):
-    """Reference ``infer`` (apa_core.py:1104-1137): one Parameters per input tuple, same order."""
-    print(f"start inferring APA events from input pickle file = {pickle_input_file}. "
-          f"Output file = {pickle_output_file}")
-    start_t = timer()
+def load_preps(pkl_input_file, kwargs):
+    """Prepared UTRs of one chunk, in file order: from <stem>.binned.npz when it is present and was made
+    from this pickle (scape_amd/binned.py), else by decoding and binning the pickle stream."""
+    from .binned import binned_path, is_current, read_binned
+    from .host import prepare_binned
     pre_para = None
     if kwargs.get("fixed_run_mode", False):                  # subsample_run (:999-1007)
         assert kwargs["pre_para_pkl_file"]
         assert os.path.exists(kwargs["pre_para_pkl_file"])
         pre_para = next(iter(read_input_chunk(kwargs["pre_para_pkl_file"])))   # first Parameters only (:1002-1003)
-    preps = [prepare_utr(df, gene_info_str=gene, pre_para=pre_para, **kwargs)
-             for gene, df in read_input_chunk(pickle_input_file)]
+    bp = binned_path(pkl_input_file)
+    if is_current(bp, pkl_input_file):
+        return [prepare_binned(b, gene_info_str=g, pre_para=pre_para, **kwargs) for g, b, _j in read_binned(bp)]
+    return [prepare_utr(df, gene_info_str=gene, pre_para=pre_para, **kwargs)
+            for gene, df in read_input_chunk(pkl_input_file)]
+
+
+def infer(pickle_input_file, pickle_output_file, **kwargs):
+    """Reference ``infer`` (apa_core.py:1104-1137): one Parameters per input tuple, same order."""
+    print(f"start inferring APA events from input pickle file = {pickle_input_file}. "
+          f"Output file = {pickle_output_file}")
+    start_t = timer()
+    preps = load_preps(pickle_input_file, kwargs)
     engine = Engine(device=kwargs.get("device"))
     results = engine.run(preps, rng_mode=kwargs.get("rng_mode", "reference"), seed=int(kwargs.get("seed", 1)),
                          re_run_mode=bool(kwargs.get("re_run_mode", True)))
@@ -239,6 +250,24 @@ def infer_pa_all(output_dir: str, toml_para_file: str = None, gpus: int = 1):
         para_dict.update(_toml.load(fh))
     para_dict.pop("output_dir", None)
     infer_all(output_dir, gpus=gpus, **para_dict)
+
+
+@click.command(name="prebin")
+@click.option('--output_dir', type=str, required=True,
+              help='output directory of prepare_input (holds pkl_input/)')
+@click.option('--workers', type=int, default=0, help='processes (0 = one per host core, at most 14)')
+def prebin(output_dir: str, workers: int = 0):
+    """Write <stem>.binned.npz beside every complete chunk of <output_dir>/pkl_input: the binned, columnar form
+    infer_pa / infer_pa_all / merge_pa read instead of the pickles when present (scape_amd/binned.py)."""
+    import glob
+
+    from .pipeline import prebin_chunk_file, shared_pool
+    files = sorted(f for f in glob.glob(os.path.join(output_dir, "pkl_input", "*.input.pkl"))
+                   if ".tmp." not in os.path.basename(f))
+    if not files:
+        raise Exception("no *.input.pkl under " + os.path.join(output_dir, "pkl_input"))
+    for path in shared_pool(workers or None).ex.map(prebin_chunk_file, files):
+        print("wrote", path)
 
 
 @click.command(name="infer_pa")

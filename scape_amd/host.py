@@ -127,16 +127,44 @@ class UtrPrep:
         return len(self.theta)
 
 
+@dataclass
+class BinnedUtr:
+    """What prepare_utr needs from the reads of one UTR - parameter independent (bin widths are fixed,
+    apa_core.py:285-327), so it can be computed once and stored (scape_amd/binned.py)."""
+    x: np.ndarray          # per bin: mean x, l, r, pa (f64) and read count
+    l: np.ndarray
+    r: np.ndarray
+    pa: np.ndarray
+    cnt: np.ndarray
+    idx: np.ndarray        # per read: its bin
+    cb_id: np.ndarray
+    read_id: np.ndarray
+    x_max: int             # over the raw reads (utr_length, :994-997)
+    l_max: int
+
+
+def bin_utr(df):
+    """DataFrame of prepare_input (columns x, l, r, pa, cb_id, read_id, ...) -> BinnedUtr."""
+    x_raw, l_raw = np.asarray(df["x"]), np.asarray(df["l"])
+    bx, bl, br, bpa, cnt, idx = bin_reads(df["x"], df["l"], df["r"], df["pa"])
+    return BinnedUtr(bx, bl, br, bpa, cnt, idx, np.array(df["cb_id"]), np.array(df["read_id"]),
+                     int(x_raw.max()), int(l_raw.max()))
+
+
 def prepare_utr(df, gene_info_str="None", pre_para=None, **kwargs):
     """subsample_run head (:994-997) + ApaModel.__init__ (:333-437) + run() grids (:940-951).
     With `pre_para` (fixed_run_mode, :999-1009 and :883-897): theta grid restricted to +-3 max(beta)
     around the given alphas, beta grid spanning the given betas, K fixed to pre_para.K."""
+    return prepare_binned(bin_utr(df), gene_info_str, pre_para, **kwargs)
+
+
+def prepare_binned(b, gene_info_str="None", pre_para=None, **kwargs):
+    """prepare_utr from already binned reads (BinnedUtr)."""
     p = model_params(kwargs)
-    x_raw, l_raw = np.asarray(df["x"]), np.asarray(df["l"])
-    utr_len = max(int(x_raw.max()) + int(l_raw.max()) + 50, kwargs.get("utr_length", -1) or -1)
+    utr_len = max(b.x_max + b.l_max + 50, kwargs.get("utr_length", -1) or -1)
     if pre_para is not None:
         utr_len = max(utr_len, int(pre_para.L))
-    bx, bl, br, bpa, cnt, idx = bin_reads(df["x"], df["l"], df["r"], df["pa"])
+    bx, bl, br, bpa, cnt, idx = b.x, b.l, b.r, b.pa, b.cnt, b.idx
     L = utr_len if utr_len > 2000 else 2000
     if not np.all((bx >= 0) & (bx < utr_len)):
         raise AssertionError("read start outside [0, utr_length)")            # (:388)
@@ -166,7 +194,7 @@ def prepare_utr(df, gene_info_str="None", pre_para=None, **kwargs):
             raise ValueError("fixed_run: the pre-specified pA sites leave no theta grid point")
     unif_ll = float(np.log((1 / L) * (1 / L) * (1 / p["max_LA"])))
     prep = UtrPrep(gene_info_str=gene_info_str, p=p, x=bx, l=bl, r=br, pa=bpa, cnt=cnt, idx=idx,
-                   cb_id=np.array(df["cb_id"]), read_id=np.array(df["read_id"]), L=int(L),
+                   cb_id=b.cb_id, read_id=b.read_id, L=int(L),
                    min_theta=min_theta, theta=theta, betas=betas, s_dis=s_dis.astype(np.float64),
                    pmf_s=pmf, unif_ll=unif_ll, fixed_run=pre_para is not None)
     # coverage peaks used by sample_alpha (:782-794) - data only, no RNG

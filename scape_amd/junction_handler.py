@@ -247,8 +247,14 @@ def _merge_pa(output_dir: str, utr_merge=True):
         for para in _load_results(os.path.join(output_dir, "pkl_output", f)):
             res_by_gene.setdefault(key_of(para.gene_info_str), {})[para.gene_info_str] = para
     print("Done read model output_dir")
+    from .binned import binned_path, is_current, read_binned
     for f in in_files:
-        for gene_info_str, df in read_input_chunk(os.path.join(output_dir, "pkl_input", f)):
+        path = os.path.join(output_dir, "pkl_input", f)
+        if is_current(binned_path(path), path):        # columnar copy of the chunk: no pickle decoding
+            stream = ((g, cols) for g, _b, cols in read_binned(binned_path(path)))
+        else:
+            stream = read_input_chunk(path)
+        for gene_info_str, df in stream:
             in_by_gene.setdefault(key_of(gene_info_str), {})[gene_info_str] = df
     print("Done read model input")
     st = timer()

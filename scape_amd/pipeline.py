@@ -35,12 +35,14 @@ def _worker_init():
 def prep_chunk_file(args):
     """Worker task: (path, kwargs) -> prepared UTRs of one prepare_input chunk, in file order."""
     path, kwargs = args
-    from .apa_core import read_input_chunk
-    from .host import prepare_utr
-    pre_para = None
-    if kwargs.get("fixed_run_mode", False):
-        pre_para = next(iter(read_input_chunk(kwargs["pre_para_pkl_file"])))
-    return [prepare_utr(df, gene_info_str=g, pre_para=pre_para, **kwargs) for g, df in read_input_chunk(path)]
+    from .apa_core import load_preps
+    return load_preps(path, kwargs)
+
+
+def prebin_chunk_file(path):
+    """Worker task: write <stem>.binned.npz for one chunk (scape_amd/binned.py)."""
+    from .binned import prebin_chunk
+    return prebin_chunk(path)
 
 
 def prep_items(args):

@@ -241,6 +241,48 @@ def test_k_arr_rules():
         assert sorted(ka[t0:t0 + 4]) == [0, 1, 2, 3]
 
 
+# ---------------------------------------------------------------- pre-binned columnar chunks
+def test_binned_chunk_gives_identical_preps_and_detects_staleness(tmp_path):
+    from scape_amd import binned
+    from scape_amd.apa_core import load_preps
+    from scape_amd.synth import synth_chunk
+    f = load_npz("fixture_chr17.npz")
+    utrs = [utr_df(f, i) for i in range(int(f["n_utr"]))] + synth_chunk(5, 400, base_seed=8, pa_rate=0.05)
+    rng = np.random.default_rng(1)
+    full = []
+    for g, df in utrs:                                  # the three columns merge_pa reads besides read_id
+        df = df.copy()
+        n = len(df)
+        df["junction"] = (rng.random(n) < 0.1).astype(np.int64)
+        df["seg1_en"] = np.where(df["junction"] == 1, rng.integers(1000, 9000, n).astype(float), np.nan)
+        df["seg2_en"] = np.where(df["junction"] == 1, rng.integers(1000, 9000, n).astype(float), np.nan)
+        full.append((g, df))
+    path = str(tmp_path / "c.100.1.1.input.pkl")
+    with open(path, "wb") as fh:
+        for it in full:
+            pickle.dump(it, fh)
+    kw = dict(n_max_apa=4, n_min_apa=1)
+    want = load_preps(path, kw)                         # no binned file yet: decodes the pickle
+    bp = binned.prebin_chunk(path)
+    assert bp == str(tmp_path / "c.100.1.1.binned.npz") and binned.is_current(bp, path)
+    with np.load(bp, allow_pickle=False) as z:          # plain arrays only
+        assert int(z["version"]) == binned.VERSION and len(z["gene_info"]) == len(full)
+    got = load_preps(path, kw)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        for k in ("x", "l", "r", "pa", "cnt", "idx", "cb_id", "read_id", "theta", "betas", "peaks", "peak_w", "s_dis"):
+            assert np.array_equal(getattr(a, k), getattr(b, k), equal_nan=True), k
+        assert (a.gene_info_str, a.L, a.min_theta, a.unif_ll, a.p) == (b.gene_info_str, b.L, b.min_theta, b.unif_ll, b.p)
+    for (g, b, cols), (g0, df) in zip(binned.read_binned(bp), full):
+        assert g == g0 and np.array_equal(cols["junction"], df["junction"])
+        assert np.array_equal(cols["seg1_en"], df["seg1_en"], equal_nan=True)
+        assert np.array_equal(cols["seg2_en"], df["seg2_en"], equal_nan=True)
+    with open(path, "ab") as fh:                        # the chunk changes -> the binned copy is stale
+        pickle.dump(full[0], fh)
+    assert not binned.is_current(bp, path)
+    assert len(load_preps(path, kw)) == len(full) + 1
+
+
 # ---------------------------------------------------------------- CLI behaviour (reference apa_core.py:78-132)
 def test_cli_error_behaviour(tmp_path):
     from click.testing import CliRunner

@@ -124,6 +124,13 @@ def test_merge_pa_cli_on_own_directory(tmp_path):
     assert len(got) == len(want) and type(got[0]).__module__ == "scape.apa_core"
     for para in got:
         _same(para, f, want[para.gene_info_str])
+    r = CliRunner().invoke(cli, ["prebin", "--output_dir", str(out), "--workers", "2"])     # columnar copies of the chunks
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    assert sorted(os.listdir(out / "pkl_input")) == ["s.100.2.1.binned.npz", "s.100.2.1.input.pkl",
+                                                     "s.100.2.2.binned.npz", "s.100.2.2.input.pkl"]
+    first = open(out / "res.gene.pkl", "rb").read()
+    r = CliRunner().invoke(cli, ["merge_pa", "--output_dir", str(out)])
+    assert r.exit_code == 0 and open(out / "res.gene.pkl", "rb").read() == first           # same bytes from the binned inputs
     r = CliRunner().invoke(cli, ["merge_pa", "--output_dir", str(out), "--utr_merge", "False"])
     assert r.exit_code == 0 and os.path.exists(out / "res.utr.pkl")
     os.remove(out / "pkl_output" / "s.100.2.2.res.pkl")
