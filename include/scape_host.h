@@ -46,6 +46,15 @@ int scape_host_init_job(uint32_t *state625, const double *peaks, const double *p
                         const double *theta, int T, int L, int n_beta, double shift_scale, double max_unif_ws,
                         int K, int n_round, int32_t *a, int32_t *b, double *w, int8_t *ka);
 
+/* One K sweep of one UTR (run() apa_core.py:965 -> em_optim0 :846-871) continuing the caller's stream:
+ * K = n_max .. n_min (descending), n_trial restarts each, written as rows of the padded job tables
+ * (jk[row] = K; a, b pitch kmax; w pitch kmax+1; ka pitch n_round; rows beyond K are left untouched -
+ * zero them first).  Returns 1 without drawing anything if an input is not covered. */
+int scape_host_sweep(uint32_t *state625, const double *peaks, const double *peak_w, int n_peak,
+                     const double *theta, int T, int L, int n_beta, double shift_scale, double max_unif_ws,
+                     int n_max, int n_min, int n_trial, int n_round, int kmax,
+                     int32_t *jk, int32_t *a, int32_t *b, double *w, int8_t *ka);
+
 /* Whole-batch plan (scape_amd/engine.py::Engine.plan): for every UTR u, seeded RandomState(seeds[u]),
  * the n_trial restarts of every K = n_max[u] .. n_min[u] (descending, apa_core.py:846-871) into the
  * padded job tables of scape_hip_batch_em, the generator state left behind, and the prune tables

@@ -46,6 +46,8 @@ SIGNATURES = {
     "scape_host_k_arr": (c_i, [P_u32, c_i, c_i, P_i8]),
     "scape_host_init_job": (c_i, [P_u32, P_d, P_d, c_i, P_d, c_i, c_i, c_i, c_d, c_d, c_i, c_i,
                                   P_i32, P_i32, P_d, P_i8]),
+    "scape_host_sweep": (c_i, [P_u32, P_d, P_d, c_i, P_d, c_i, c_i, c_i, c_d, c_d, c_i, c_i, c_i, c_i, c_i,
+                               P_i32, P_i32, P_i32, P_d, P_i8]),
     "scape_host_plan": (c_i, [ctypes.POINTER(PlanArgs)]),
 }
 

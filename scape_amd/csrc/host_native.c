@@ -296,6 +296,33 @@ int scape_host_init_job(uint32_t *state625, const double *peaks, const double *p
     return rc;
 }
 
+/* One K sweep (run() :965 -> em_optim0 :846-871) continuing the caller's stream: K = n_max .. n_min, n_trial
+ * restarts each, rows in that order, pitch kmax (w: kmax+1).  Nothing is drawn when it returns 1. */
+int scape_host_sweep(uint32_t *state625, const double *peaks, const double *peak_w, int n_peak,
+                     const double *theta, int T, int L, int n_beta, double shift_scale, double max_unif_ws,
+                     int n_max, int n_min, int n_trial, int n_round, int kmax,
+                     int32_t *jk, int32_t *a, int32_t *b, double *w, int8_t *ka)
+{
+    utr_in q = {peaks, peak_w, theta, n_peak, T, L, n_beta, shift_scale, max_unif_ws};
+    if (n_min < 1 || n_max < n_min || n_max > kmax || kmax > SCAPE_HOST_MAX_K || n_trial < 1 || n_round < 0) return 1;
+    for (int K = n_max; K >= n_min; K--)
+        if (!utr_supported(&q, K)) return 1;
+    scratch sc;
+    memset(&sc, 0, sizeof(sc));
+    mt_t s;
+    memcpy(&s, state625, sizeof(s));
+    int rc = 0;
+    size_t j = 0;
+    for (int K = n_max; K >= n_min && !rc; K--)
+        for (int t = 0; t < n_trial && !rc; t++, j++) {
+            jk[j] = K;
+            rc = draw_init_job(&s, &q, K, n_round, &sc, a + j * kmax, b + j * kmax, w + j * (kmax + 1), ka + j * n_round);
+        }
+    scratch_free(&sc);
+    if (!rc) memcpy(state625, &s, sizeof(s));
+    return rc;
+}
+
 /* ------------------------------------------------------------------ whole-batch plan, threaded over UTRs */
 typedef struct {
     const struct scape_host_plan_args *A;

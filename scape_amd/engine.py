@@ -91,6 +91,22 @@ def pack_jobs(jobs):
     return PackedJobs(i32([j.u for j in jobs]), i32([j.K for j in jobs]), i32([int(j.fixed) for j in jobs]), a, b, w, ka)
 
 
+def concat_packed(packs):
+    """Stack job tables of different K pitch into one (rows keep their order)."""
+    if len(packs) == 1:
+        return packs[0]
+    n, kmax = sum(len(p) for p in packs), max(p.kmax for p in packs)
+    a, b = np.zeros((n, kmax), np.int32), np.zeros((n, kmax), np.int32)
+    w = np.zeros((n, kmax + 1), np.float64)
+    lo = 0
+    for p in packs:
+        hi, k = lo + len(p), p.kmax
+        a[lo:hi, :k], b[lo:hi, :k], w[lo:hi, :k + 1] = p.a, p.b, p.w
+        lo = hi
+    cat = lambda name: np.concatenate([getattr(p, name) for p in packs])   # noqa: E731
+    return PackedJobs(cat("ju"), cat("jk"), cat("jf"), a, b, w, cat("ka"))
+
+
 class HipBatch:
     """A batch of UTRs resident on the GPU (scape_hip_batch_* calls)."""
 
@@ -251,6 +267,31 @@ class _Sweep:
             jobs.append(_Job(self.u, Kp, True, f.a_idx[keep].astype(np.int32), f.b_idx[keep].astype(np.int32), w, ka))
         self.n_jobs += len(jobs)
         return jobs
+
+    def make_packed(self):
+        """make_jobs as padded tables (one native call per sweep, engine._drive's fast path)."""
+        q = self.prep
+        if self.stage == "sweep" and hasattr(self.sampler, "sweep"):
+            jk, a, b, w, ka = self.sampler.sweep(q, self.n_max, self.n_min)
+            n = len(jk)
+            self.n_jobs += n
+            return PackedJobs(np.full(n, self.u, np.int32), jk, np.zeros(n, np.int32), a, b, w, ka)
+        return pack_jobs(self.make_jobs())
+
+    def absorb_packed(self, pj, out, lo, hi):
+        """absorb for rows [lo, hi) of a packed EM result: only the winner becomes a Fit."""
+        if self.stage == "sweep":
+            with np.errstate(over="ignore"):
+                grid = out[3][lo:hi].astype(np.float32).reshape(-1, N_TRIAL)     # float32 bic_arr (:849, :945)
+            tb = np.argmin(grid, axis=1)                                         # em_optim0 (:865)
+            kb = int(np.argmin(grid[np.arange(len(tb)), tb]))                    # run (:972)
+            self.best = HipBatch.fit_at(pj, out, lo + kb * N_TRIAL + int(tb[kb]))
+            if not self.prep.fixed_run and np.any(self.best.ws[:self.best.K] < self.prep.p["min_ws"]):
+                self.stage = "prune"
+                return
+        elif self.stage == "prune":
+            self.best = HipBatch.fit_at(pj, out, lo)
+        self._after_fit()
 
     def absorb(self, fits):
         q = self.prep
@@ -420,14 +461,13 @@ class Engine:
             done_sweeps = []
             while queues:
                 heads = [q[0] for q in queues.values()]
-                jobs, spans = [], []
-                for sw in heads:
-                    js = sw.make_jobs()
-                    spans.append((len(jobs), len(jobs) + len(js)))
-                    jobs.extend(js)
-                fits = batch.em(jobs)
-                for sw, (a, b) in zip(heads, spans):
-                    sw.absorb(fits[a:b])
+                packs = [sw.make_packed() for sw in heads]
+                pj = concat_packed(packs)
+                out = batch.em_packed(pj)
+                lo = 0
+                for sw, pk in zip(heads, packs):
+                    sw.absorb_packed(pj, out, lo, lo + len(pk))
+                    lo += len(pk)
                 for si in list(queues):
                     if queues[si][0].done:
                         done_sweeps.append(queues[si].pop(0))
@@ -653,6 +693,15 @@ class Engine:
     @staticmethod
     def _drive(batch, sweeps):
         pending = list(sweeps)
+        while pending and all(sw.trace is None for sw in pending):      # fast path: padded tables end to end
+            packs = [sw.make_packed() for sw in pending]
+            pj = concat_packed(packs)
+            out = batch.em_packed(pj)
+            lo = 0
+            for sw, pk in zip(pending, packs):
+                sw.absorb_packed(pj, out, lo, lo + len(pk))
+                lo += len(pk)
+            pending = [sw for sw in pending if not sw.done]
         while pending:
             jobs, spans = [], []
             for sw in pending:

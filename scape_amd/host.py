@@ -301,6 +301,39 @@ class FastSampler:
             self._reload()
         return ka
 
+    def sweep(self, prep, n_max, n_min):
+        """All restarts of one K sweep (K = n_max .. n_min, N_TRIAL each) as padded tables with pitch n_max:
+        (K per row, alpha idx, beta idx, ws, k_arr) - one native call instead of one per restart."""
+        h, p = self._h, prep.p
+        pk, pw, th = self._arrays(prep)
+        n = (n_max - n_min + 1) * N_TRIAL
+        jk, a, b = np.zeros(n, np.int32), np.zeros((n, n_max), np.int32), np.zeros((n, n_max), np.int32)
+        w, ka = np.zeros((n, n_max + 1), np.float64), np.zeros((n, N_ROUND), np.int8)
+        rc = 1
+        if n_max <= h.MAX_K:
+            rc = self._lib.scape_host_sweep(self._sp, h.ptr(pk, h.P_d), h.ptr(pw, h.P_d), len(pk), h.ptr(th, h.P_d),
+                                            len(th), int(prep.L), len(prep.betas), float(5 * p["beta_step"]),
+                                            float(p["max_unif_ws"]), n_max, n_min, N_TRIAL, N_ROUND, n_max,
+                                            h.ptr(jk, h.P_i32), h.ptr(a, h.P_i32), h.ptr(b, h.P_i32), h.ptr(w, h.P_d),
+                                            h.ptr(ka, h.P_i8))
+        if rc:                                           # declined: restart by restart (numpy draws / raises)
+            i = 0
+            for K in range(n_max, n_min - 1, -1):
+                for _ in range(N_TRIAL):
+                    jk[i] = K
+                    a[i, :K], b[i, :K], w[i, :K + 1], ka[i] = self.init_job(prep, K)
+                    i += 1
+        return jk, a, b, w, ka
+
+    @staticmethod
+    def _arrays(prep):
+        c = prep.__dict__.get("_native")
+        if c is None:
+            c = (np.ascontiguousarray(prep.peaks, dtype=np.float64), np.ascontiguousarray(prep.peak_w, dtype=np.float64),
+                 np.ascontiguousarray(prep.theta, dtype=np.float64))
+            prep.__dict__["_native"] = c
+        return c
+
     def init_job(self, prep, K):
         h, p = self._h, prep.p
         c = prep.__dict__.get("_native")

@@ -204,6 +204,29 @@ def test_native_sampler_equals_numpy_stream():
         FastSampler(np.random.RandomState(1)).init_job(q, q.L + len(q.peaks) + 5)
 
 
+def test_native_sweep_equals_job_by_job_draws():
+    """FastSampler.sweep (one native call per K sweep, the reference-stream fast path) == init_job per restart."""
+    from scape_amd.host import FastSampler, Sampler, prepare_utr
+    from scape_amd.synth import synth_chunk
+    for u, (g, df) in enumerate(synth_chunk(6, 500, base_seed=21)):
+        q = prepare_utr(df, g, n_max_apa=12, n_min_apa=1)
+        r1, r2 = np.random.RandomState(9 + u), np.random.RandomState(9 + u)
+        s1, s2 = Sampler(r1), FastSampler(r2)
+        for n_max, n_min in ((12, 1), (5, 2), (14, 12), (3, 3)):
+            jk, a, b, w, ka = s2.sweep(q, n_max, n_min)
+            i = 0
+            for K in range(n_max, n_min - 1, -1):
+                for _ in range(10):
+                    ea, eb, ew, eka = s1.init_job(q, K)
+                    assert jk[i] == K and np.array_equal(a[i, :K], ea) and np.array_equal(b[i, :K], eb)
+                    assert np.array_equal(w[i, :K + 1], ew) and np.array_equal(ka[i], eka)
+                    assert not a[i, K:].any() and not w[i, K + 1:].any()
+                    i += 1
+            assert i == len(jk)
+        g1, g2 = r1.get_state(), s2.rs.get_state()
+        assert np.array_equal(g1[1], g2[1]) and g1[2] == g2[2]
+
+
 def test_native_plan_equals_python_plan():
     """Engine.plan (scape_host_plan, threaded) == Engine.plan_python (numpy RandomState), table for table,
     for mixed K ranges and seeds at the 32-bit edge."""
