@@ -7,7 +7,7 @@ from scape_amd.engine import Engine
 from scape_amd.host import prepare_utr
 from scape_amd.synth import synth_utr
 
-U, F = 96, 8
+U, F = 48, 32
 kw = dict(n_max_apa=10, n_min_apa=1)
 files = []
 for f in range(F):
