@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--kcap", type=int, default=10)
     ap.add_argument("--base-seed", type=int, default=20250225)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-utrs", type=int, default=2048,
+    ap.add_argument("--e2e-utrs", type=int, default=16384,
                     help="UTRs of the untimed-by-the-metric end-to-end leg (chunk files -> .res.pkl), 0 = skip")
     ap.add_argument("--e2e-workers", type=int, default=0, help="prep processes of the end-to-end leg (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU work for the baseline sample")
