@@ -1034,6 +1034,31 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         HIPCHK(hipEventRecord(ev_fork, c->stream));
         HIPCHK(hipStreamWaitEvent(c->stream2, ev_fork, 0));
     }
+    if (!any_m) {
+        // only fixed-inference jobs (the ws-only re-fits of rm_component): all rounds in one launch
+        const int ngj = (int)nj;
+        const int32_t *jl = c->e_ujlist.as<int32_t>();
+        if (fine && ev_begin(c, 4)) return 1;
+#define LAUNCH_ALL(CM)                                                                                         \
+    hipLaunchKernelGGL(k2_estep_all_rounds<CM>, dim3((unsigned)(((ngj + 7) / 8) * 8)), dim3(64), 0, c->stream, \
+                       c->d_desc.as<UtrDesc>(), c->prm, c->d_cnt.as<double>(), c->d_M.as<double>(), kmax,      \
+                       c->j_utr.as<int32_t>(), c->j_K.as<int32_t>(), c->j_fixed.as<int32_t>(),                 \
+                       c->j_a.as<int32_t>(), c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(), \
+                       S, c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                 \
+                       c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                    \
+                       c->d_counters.as<unsigned long long>(), jl, ngj)
+        if (kmax + 1 <= 4) LAUNCH_ALL(4);
+        else if (kmax + 1 <= 8) LAUNCH_ALL(8);
+        else if (kmax + 1 <= 12) LAUNCH_ALL(12);
+        else if (kmax + 1 <= 16) LAUNCH_ALL(16);
+        else if (kmax + 1 <= 24) LAUNCH_ALL(24);
+        else LAUNCH_ALL(32);
+#undef LAUNCH_ALL
+        HIPCHK(hipGetLastError());
+        if (fine && ev_end(c, 4)) return 1;
+        if (dbg) (void)hipFree(dbg);
+        return 0;
+    }
     unsigned long long executed_prev = 0;
     int rc = 0;
     for (int r = 0; r <= nround && !rc; ++r) {
