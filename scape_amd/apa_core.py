@@ -199,7 +199,14 @@ def infer_files(files, output_dir, device=None, files_in_flight=32, workers=None
 
 def _infer_files_worker(rank, files, output_dir, kwargs, workers):
     os.environ["LOCAL_RANK"] = str(rank)
-    infer_files(files, output_dir, device=rank, workers=workers, **kwargs)
+    from . import _lib
+    from .pipeline import close_shared_pool, shared_pool
+    shared_pool(workers)                                   # prep workers first: they never see a HIP context
+    try:
+        device = rank % max(1, _lib.device_count())        # more workers than GPUs only happens in tests
+        infer_files(files, output_dir, device=device, workers=workers, **kwargs)
+    finally:
+        close_shared_pool()                                # or this process never gets past its exit join
 
 
 def infer_all(output_dir, gpus=1, **kwargs):
@@ -218,8 +225,14 @@ def infer_all(output_dir, gpus=1, **kwargs):
     if gpus == 1:
         infer_files(files, output_dir, device=kwargs.pop("device", None), **kwargs)
         return files
-    ctx = mp.get_context("spawn")
-    workers = max(1, (os.cpu_count() or 1) // gpus - 2)          # prep processes per GPU worker
+    # fork-server children: no exec from this process (which may already hold a HIP context, e.g. under pytest),
+    # and the workers are born without one
+    ctx = mp.get_context("forkserver")
+    try:
+        n_cpu = len(os.sched_getaffinity(0))                      # the cores this process may use, not the host's
+    except AttributeError:
+        n_cpu = os.cpu_count() or 1
+    workers = max(1, min(14, n_cpu // gpus - 2))               # prep processes per GPU worker
     procs = [ctx.Process(target=_infer_files_worker,
                          args=(r, [files[i] for i in shards[r]], output_dir, kwargs, workers))
              for r in range(gpus) if shards[r]]

@@ -344,6 +344,7 @@ class Engine:
         else:
             self.ctx = _lib.default_context(device)
         self.mem_fraction = mem_fraction
+        self.own_context = own_context
         self.sweep_lock = None       # optional threading.Lock shared by engines on one device (pipeline.py)
 
     def _budget(self):
@@ -356,6 +357,11 @@ class Engine:
     def utr_bytes(q):
         npad = (q.N + 15) // 16 * 16
         return 8 * npad * q.T * (len(q.betas) + 2) + 48 * q.N
+
+    def close(self):
+        """Release a private library handle (no-op for the shared per-device handle)."""
+        if self.own_context:
+            self.ctx.close()
 
     def load(self, preps):
         """Upload one wave of prepared UTRs (scape_hip_batch_load)."""

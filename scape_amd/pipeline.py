@@ -86,6 +86,15 @@ def shared_pool(workers=None):
     return _shared
 
 
+def close_shared_pool():
+    """Shut the process-wide pool down now.  Needed at the end of multiprocessing children: they leave through
+    os._exit() after joining their own child processes, which never end unless the executor is shut down."""
+    global _shared
+    if _shared is not None:
+        _shared.close()
+        _shared = None
+
+
 def synth_chunk_file(args):
     """Worker task for benchmarks/tests: write UTRs [start, start+count) of the synthetic stream
     (scape_amd/synth.py) as one prepare_input-style chunk file; returns the path."""
@@ -201,6 +210,10 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
                 pass
         finally:
             q_out.put(_STOP)
+            try:
+                eng.close()                           # a private library handle is released with its thread
+            except Exception:                         # noqa: BLE001 - engine_factory itself may have failed
+                pass
 
     tp = threading.Thread(target=producer, name="scape-plan", daemon=True)
     tgs = [threading.Thread(target=gpu_stage, name=f"scape-gpu{i}", daemon=True) for i in range(gpu_streams)]

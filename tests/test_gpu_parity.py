@@ -503,6 +503,44 @@ def test_infer_pa_all_equals_per_file_runs(tmp_path):
             assert np.array_equal(a.lb_arr, b.lb_arr)
 
 
+def test_infer_pa_all_two_worker_processes(tmp_path):
+    """--gpus 2: chunk files sharded over two worker processes (each with its own prep pool and library handle;
+    on a one-GPU box both use device 0).  Every file's result equals the single-process run."""
+    from click.testing import CliRunner
+    from scape.cli import cli
+    from scape_amd.synth import synth_chunk
+    outs = []
+    for gpus in (1, 2):
+        out = tmp_path / f"g{gpus}"
+        (out / "pkl_input").mkdir(parents=True)
+        (out / "parameters.toml").write_text('n_max_apa = 3\nre_run_mode = true\nrng_mode = "per_utr"\nseed = 11\n')
+        for fi, n in enumerate((6, 2, 5, 3)):
+            with open(out / "pkl_input" / f"m{fi}.100.4.{fi + 1}.input.pkl", "wb") as fh:
+                for g, df in synth_chunk(n, 260 + 30 * fi, k_cap=3, base_seed=500 + 10 * fi, pa_rate=0.04):
+                    pickle.dump((g, df), fh)
+        r = CliRunner().invoke(cli, ["infer_pa_all", "--output_dir", str(out), "--gpus", str(gpus)])
+        assert r.exit_code == 0, r.output + repr(r.exception)
+        outs.append(out)
+
+    def load(p):
+        res = []
+        with open(p, "rb") as fh:
+            while True:
+                try:
+                    res.append(pickle.load(fh))
+                except EOFError:
+                    return res
+    names = sorted(os.listdir(outs[0] / "pkl_output"))
+    assert names == sorted(os.listdir(outs[1] / "pkl_output")) and len(names) == 4
+    for n in names:
+        a, b = load(outs[0] / "pkl_output" / n), load(outs[1] / "pkl_output" / n)
+        assert len(a) == len(b) > 0
+        for x, y in zip(a, b):
+            assert x.gene_info_str == y.gene_info_str and x.K == y.K and x.bic == y.bic
+            assert np.array_equal(x.alpha_arr, y.alpha_arr) and np.array_equal(x.ws, y.ws)
+            assert np.array_equal(x.label_arr, y.label_arr)
+
+
 def test_pipelined_per_utr_mode_equals_engine_run(tmp_path, oracle):
     """rng_mode='per_utr' through the host pipeline (prep processes -> native planner -> GPU thread ->
     writer, batches that straddle file boundaries) writes exactly what Engine.run gives for each file on

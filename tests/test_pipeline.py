@@ -87,3 +87,23 @@ def test_pipeline_propagates_worker_and_gpu_errors(tmp_path, pool):
     with pytest.raises(RuntimeError, match="device lost"):
         pipeline.run_pipeline([(f, kw) for f in files], pipeline.prep_chunk_file, lambda ti, res: None, Boom, pool,
                               batch_utrs=2)
+
+
+def _child_uses_and_closes_pool():
+    from scape_amd import pipeline
+    pool = pipeline.shared_pool(2)
+    assert list(pool.ex.map(int, [1, 2, 3])) == [1, 2, 3]
+    pipeline.close_shared_pool()
+
+
+def test_worker_process_exits_after_closing_its_pool():
+    """A multiprocessing child joins its own children before os._exit(): without close_shared_pool() the prep
+    workers keep it alive for ever (what `infer_pa_all --gpus N` workers do in their finally clause)."""
+    import multiprocessing as mp
+    p = mp.get_context("forkserver").Process(target=_child_uses_and_closes_pool)
+    p.start()
+    p.join(60)
+    alive = p.is_alive()
+    if alive:
+        p.kill()
+    assert not alive and p.exitcode == 0
