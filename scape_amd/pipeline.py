@@ -26,10 +26,20 @@ from . import _hostlib
 _STOP = object()
 
 
-def _worker_init():
+def _worker_init(owner_pid):
     # prep workers never touch the GPU; keep numpy's own thread pools out of the way
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+    def watch():                                      # the workers are children of the fork server, not of the
+        import time                                   # process that owns the pool: leave when that one is gone
+        while True:
+            time.sleep(2.0)
+            try:
+                os.kill(owner_pid, 0)
+            except OSError:
+                os._exit(0)
+    threading.Thread(target=watch, name="scape-owner-watch", daemon=True).start()
 
 
 def prep_chunk_file(args):
@@ -59,7 +69,7 @@ class PrepPool:
     def __init__(self, workers=None):
         self.workers = workers if workers else max(1, _hostlib.host_threads() - 2)
         self.ex = ProcessPoolExecutor(self.workers, mp_context=mp.get_context("forkserver"),
-                                      initializer=_worker_init)
+                                      initializer=_worker_init, initargs=(os.getpid(),))
         list(self.ex.map(int, range(self.workers)))            # bring the workers up now
 
     def close(self):
