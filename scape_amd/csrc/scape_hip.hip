@@ -828,7 +828,7 @@ struct scape_hip_ctx {
     DevBuf l_utr, l_K, l_a, l_b, l_ws, l_labels;
     // lock-step EM state (em_lockstep.inc)
     DevBuf e_ia, e_ib, e_sia, e_sib, e_ws, e_slw, e_lb, e_ell, e_nlb, e_status, e_rdk, e_rdlo, e_rdhi, e_rdm,
-        e_rdlw, e_rdsv, e_rdn0, e_rdn1, e_V, e_Vsuf, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist;
+        e_rdlw, e_rdsv, e_rdn0, e_rdn1, e_V, e_Vsuf, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist, e_active;
     std::vector<EventPair> ev[6];
     double ms_acc[6] = {0, 0, 0, 0, 0, 0};
     int n_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -977,8 +977,15 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         c->e_rdk.ensure(nj * 4) || c->e_rdlo.ensure(nj * 4) || c->e_rdhi.ensure(nj * 4) || c->e_rdm.ensure(nj * 4) ||
         c->e_rdlw.ensure(nj * 8) || c->e_rdsv.ensure(nj * 8) || c->e_rdn0.ensure(nj * 4) || c->e_rdn1.ensure(nj * 4) || c->e_V.ensure(vtot * 8) || c->e_Vsuf.ensure((vtot / 16 + nj + 1) * 8) || c->e_voff.ensure(nj * 8) ||
         c->e_ptscore.ensure(pttot * 8) || c->e_ptrow.ensure(pttot * 4) || c->e_ptoff.ensure(nj * 8) ||
-        c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4))
+        c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4) || c->e_active.ensure((size_t)c->n_utr * 4))
         return 1;
+    // UTRs that have at least one job in this call, in index order: the M-step grid runs over this list, so a call
+    // that touches a few UTRs of a large resident batch (reference-stream mode) still uses every XCD
+    std::vector<int32_t> active;
+    for (int u = 0; u < c->n_utr; ++u)
+        if (ujoff[u + 1] > ujoff[u]) active.push_back(u);
+    const int n_active = (int)active.size();
+    if (n_active) HIPCHK(hipMemcpyAsync(c->e_active.p, active.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->e_voff.p, voff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->e_ptoff.p, ptoff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->e_ujoff.p, ujoff.data(), (c->n_utr + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -1025,7 +1032,10 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     // rate, which leaves no room for E-step waves on the same SIMD - so it is off unless requested.
     const bool split = any_m && !fine && !debug && c->n_utr >= 16 && n_jobs >= 2048 && getenv("SCAPE_HIP_TWO_STREAMS");
     const int n_grp = split ? 2 : 1;
-    int g_u0[3] = {0, split ? c->n_utr / 2 : c->n_utr, c->n_utr};
+    // groups are halves of the ACTIVE list; g_u0 holds the UTR index bounds of each half for the job ranges
+    const int a_half = split ? n_active / 2 : n_active;
+    int g_a0[3] = {0, a_half, n_active};
+    int g_u0[3] = {0, (split && a_half < n_active) ? active[a_half] : c->n_utr, c->n_utr};
     hipStream_t g_stream[2] = {c->stream, c->stream2};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     if (split) {
@@ -1089,9 +1099,9 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             if (fine && ev_end(c, 4)) return 1;
             if (r < nround && any_m) {
                 if (fine && ev_begin(c, 5)) return 1;
-                const int nu = u1 - u0;
+                const int nu = g_a0[g + 1] - g_a0[g];
                 hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max)), dim3(256), 0, st,
-                                   c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), u0, nu, tiles_max,
+                                   c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, tiles_max,
                                    c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo,
                                    S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row,
                                    c->d_tile_nend.as<int32_t>(), dbg);
@@ -1173,7 +1183,7 @@ int scape_hip_batch_free(scape_hip_ctx *c) {
                      &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels, &c->e_ia, &c->e_ib, &c->e_sia, &c->e_sib,
                      &c->e_ws, &c->e_slw, &c->e_lb, &c->e_ell, &c->e_nlb, &c->e_status, &c->e_rdk, &c->e_rdlo,
                      &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_rdn0, &c->e_rdn1, &c->e_V, &c->e_Vsuf, &c->e_voff, &c->e_ptscore,
-                     &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist};
+                     &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist, &c->e_active};
     for (DevBuf *b : all) b->release();
     c->loaded = c->built = false;
     c->n_utr = 0;

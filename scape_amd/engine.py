@@ -333,6 +333,7 @@ class _Sweep:
 
 class Engine:
     """infer_pa for lists of UTRs on one GPU."""
+    defer_prunes = True      # reference-stream modes: run the ws-only re-fits of a wave in one launch at its end
 
     def __init__(self, device=None, mem_fraction=0.7, own_context=False):
         """own_context: create a private library handle (own HIP stream and device buffers) instead of the
@@ -404,8 +405,10 @@ class Engine:
                     smp = shared if shared is not None else FastSampler(np.random.RandomState(seeds[gi]))
                     sweeps.append(_Sweep(u, preps[gi], smp, re_run_mode, self.traces[gi] if keep_trace else None))
                 if rng_mode == "reference":
+                    deferred = []
                     for sw in sweeps:
-                        self._drive(batch, [sw])
+                        self._drive(batch, [sw], deferred)
+                    self._finish_deferred(batch, deferred)
                 else:
                     self._drive(batch, sweeps)
                 labs = batch.labels([(sw.u, sw.best) for sw in sweeps])
@@ -464,7 +467,7 @@ class Engine:
             queues = {}
             for u, g in enumerate(wave):
                 queues.setdefault(owner[g], []).append(_Sweep(u, flat[g], samplers[owner[g]], re_run_mode))
-            done_sweeps = []
+            done_sweeps, deferred = [], []
             while queues:
                 heads = [q[0] for q in queues.values()]
                 packs = [sw.make_packed() for sw in heads]
@@ -474,11 +477,14 @@ class Engine:
                 for sw, pk in zip(heads, packs):
                     sw.absorb_packed(pj, out, lo, lo + len(pk))
                     lo += len(pk)
+                self._defer_prunes(heads, deferred)             # re-fits wait for the end of the wave
+                waiting = {id(sw) for sw, _pk in deferred}
                 for si in list(queues):
-                    if queues[si][0].done:
+                    if queues[si][0].done or id(queues[si][0]) in waiting:
                         done_sweeps.append(queues[si].pop(0))
                         if not queues[si]:
                             del queues[si]
+            self._finish_deferred(batch, deferred)
             labs = batch.labels([(sw.u, sw.best) for sw in done_sweeps])
             for sw in done_sweeps:
                 g = wave[sw.u]
@@ -697,7 +703,35 @@ class Engine:
         return res
 
     @staticmethod
-    def _drive(batch, sweeps):
+    def _defer_prunes(sweeps, deferred):
+        """A sweep that ends in a prune is finished as far as the random stream is concerned: the re-fit's
+        tables are drawn now (stream order, rm_component :843 -> :709 -> :720), its outcome feeds nothing but
+        the UTR's own result (K' < n_max, so the re-run rule cannot fire) - so the EM call itself can wait and
+        share one launch with the other re-fits of the wave.  Returns the sweeps still in progress."""
+        rest = []
+        for sw in sweeps:
+            if sw.done:
+                continue
+            if sw.stage == "prune" and sw.trace is None and Engine.defer_prunes:
+                deferred.append((sw, sw.make_packed()))
+            else:
+                rest.append(sw)
+        return rest
+
+    @staticmethod
+    def _finish_deferred(batch, deferred):
+        if not deferred:
+            return
+        pj = concat_packed([pk for _sw, pk in deferred])
+        out = batch.em_packed(pj)
+        lo = 0
+        for sw, pk in deferred:
+            sw.absorb_packed(pj, out, lo, lo + len(pk))
+            lo += len(pk)
+        deferred.clear()
+
+    @staticmethod
+    def _drive(batch, sweeps, deferred=None):
         pending = list(sweeps)
         while pending and all(sw.trace is None for sw in pending):      # fast path: padded tables end to end
             packs = [sw.make_packed() for sw in pending]
@@ -708,6 +742,8 @@ class Engine:
                 sw.absorb_packed(pj, out, lo, lo + len(pk))
                 lo += len(pk)
             pending = [sw for sw in pending if not sw.done]
+            if deferred is not None:
+                pending = Engine._defer_prunes(pending, deferred)
         while pending:
             jobs, spans = [], []
             for sw in pending:
