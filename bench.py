@@ -141,8 +141,15 @@ def end_to_end(args, pool, dev):
         prebinned = dict(value=args.e2e_utrs / dt2, seconds=dt2, prebin_s=t_prebin,
                          binned_bytes=sum(os.path.getsize(f) for f in bfiles),
                          stages_s={k: round(v, 3) for k, v in st2.items() if k.endswith("_s")})
+        # and in the CLI's default mode: every chunk file keeps the reference's own random stream (results equal
+        # the reference's run of that file), the files' current UTRs share the launches (Engine.run_streams)
+        t0 = time.perf_counter()
+        infer_files(files, root, device=dev, rng_mode="reference", seed=1, re_run_mode=False,
+                    n_max_apa=args.kcap, n_min_apa=1)
+        dt3 = time.perf_counter() - t0
+        reference_streams = dict(value=args.e2e_utrs / dt3, seconds=dt3, chunk_files_in_flight=min(128, len(files)))
         return dict(value=args.e2e_utrs / dt, unit="UTRs/s", utrs=args.e2e_utrs, seconds=dt, prep_workers=pool.workers,
-                    from_prebinned_chunks=prebinned,
+                    from_prebinned_chunks=prebinned, reference_streams=reference_streams,
                     chunk_files=len(files), input_bytes=in_bytes, output_bytes=out_bytes,
                     stages_s={k: round(v, 3) for k, v in st.items() if k.endswith("_s")}, gpu_batches=st.get("n_batch"),
                     includes="read+unpickle chunk files, binning, coverage peaks, restart sampling, H2D, Phase A/B, "

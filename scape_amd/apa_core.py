@@ -186,14 +186,21 @@ def infer_files(files, output_dir, device=None, files_in_flight=128, workers=Non
                      stats=stats)             # two engines share the device (pipeline.run_pipeline)
         return written
     engine = Engine(device=device)
-    groups = [tasks[i:i + files_in_flight] for i in range(0, len(tasks), files_in_flight)]
+    # groups of chunk files share launches; at least three groups (when there are enough files) so that the prep
+    # of the next group and the writing of the previous one overlap the GPU work of the current one
+    from concurrent.futures import ThreadPoolExecutor
+    per_group = min(files_in_flight, max(16, -(-len(tasks) // 3)))
+    groups = [tasks[i:i + per_group] for i in range(0, len(tasks), per_group)]
     pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[0]] if groups else []
-    for gi, group in enumerate(groups):
-        streams = [(fu.result(), seed) for fu in pending]
-        pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[gi + 1]] if gi + 1 < len(groups) else []
-        per_file = engine.run_streams(streams, re_run_mode=re_run)
-        for (f, _kw), results in zip(group, per_file):
-            written.append(_write_results(output_dir, f, results))
+    with ThreadPoolExecutor(1) as writer:
+        writes = []
+        for gi, group in enumerate(groups):
+            streams = [(fu.result(), seed) for fu in pending]
+            pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[gi + 1]] if gi + 1 < len(groups) else []
+            per_file = engine.run_streams(streams, re_run_mode=re_run)
+            for (f, _kw), results in zip(group, per_file):
+                writes.append(writer.submit(_write_results, output_dir, f, results))
+        written = [w.result() for w in writes]
     return written
 
 
