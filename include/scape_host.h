@@ -55,6 +55,21 @@ int scape_host_sweep(uint32_t *state625, const double *peaks, const double *peak
                      int n_max, int n_min, int n_trial, int n_round, int kmax,
                      int32_t *jk, int32_t *a, int32_t *b, double *w, int8_t *ka);
 
+/* scape_host_sweep for many independent streams at once (the current UTRs of several chunk files,
+ * scape_amd/engine.py::Engine.run_streams), spread over n_threads host threads.  Every item needs its own
+ * state625; status is set per item (0 ok / 1 declined, nothing drawn). */
+struct scape_host_sweep_item {
+    uint32_t *state625;
+    const double *peaks, *peak_w, *theta;
+    int32_t n_peak, T, L, n_beta;
+    double shift_scale, max_unif_ws;
+    int32_t n_max, n_min, kmax, status;
+    int32_t *jk, *a, *b;
+    double *w;
+    int8_t *ka;
+};
+int scape_host_sweep_batch(struct scape_host_sweep_item *items, int n, int n_trial, int n_round, int n_threads);
+
 /* Whole-batch plan (scape_amd/engine.py::Engine.plan): for every UTR u, seeded RandomState(seeds[u]),
  * the n_trial restarts of every K = n_max[u] .. n_min[u] (descending, apa_core.py:846-871) into the
  * padded job tables of scape_hip_batch_em, the generator state left behind, and the prune tables

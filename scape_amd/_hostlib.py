@@ -37,6 +37,15 @@ class PlanArgs(ctypes.Structure):
                 ("status", P_i32)]
 
 
+class SweepItem(ctypes.Structure):
+    """struct scape_host_sweep_item"""
+    _fields_ = [("state625", P_u32), ("peaks", P_d), ("peak_w", P_d), ("theta", P_d),
+                ("n_peak", c_i32), ("T", c_i32), ("L", c_i32), ("n_beta", c_i32),
+                ("shift_scale", c_d), ("max_unif_ws", c_d),
+                ("n_max", c_i32), ("n_min", c_i32), ("kmax", c_i32), ("status", c_i32),
+                ("jk", P_i32), ("a", P_i32), ("b", P_i32), ("w", P_d), ("ka", P_i8)]
+
+
 # name -> (restype, argtypes); must list every symbol include/scape_host.h declares
 SIGNATURES = {
     "scape_host_abi_version": (c_i, []),
@@ -48,6 +57,7 @@ SIGNATURES = {
                                   P_i32, P_i32, P_d, P_i8]),
     "scape_host_sweep": (c_i, [P_u32, P_d, P_d, c_i, P_d, c_i, c_i, c_i, c_d, c_d, c_i, c_i, c_i, c_i, c_i,
                                P_i32, P_i32, P_i32, P_d, P_i8]),
+    "scape_host_sweep_batch": (c_i, [ctypes.POINTER(SweepItem), c_i, c_i, c_i, c_i]),
     "scape_host_plan": (c_i, [ctypes.POINTER(PlanArgs)]),
 }
 

@@ -323,6 +323,52 @@ int scape_host_sweep(uint32_t *state625, const double *peaks, const double *peak
     return rc;
 }
 
+/* Many sweeps at once, one per item, every item with its OWN generator state (independent streams: the current
+ * UTRs of different chunk files); items are spread over host threads. */
+typedef struct {
+    struct scape_host_sweep_item *items;
+    int n, n_trial, n_round, next;
+    pthread_mutex_t mu;
+} sweep_shared;
+
+static void *sweep_worker(void *arg)
+{
+    sweep_shared *S = (sweep_shared *)arg;
+    for (;;) {
+        pthread_mutex_lock(&S->mu);
+        int i = S->next++;
+        pthread_mutex_unlock(&S->mu);
+        if (i >= S->n) break;
+        struct scape_host_sweep_item *it = &S->items[i];
+        it->status = scape_host_sweep(it->state625, it->peaks, it->peak_w, it->n_peak, it->theta, it->T, it->L,
+                                      it->n_beta, it->shift_scale, it->max_unif_ws, it->n_max, it->n_min, S->n_trial,
+                                      S->n_round, it->kmax, it->jk, it->a, it->b, it->w, it->ka);
+    }
+    return NULL;
+}
+
+int scape_host_sweep_batch(struct scape_host_sweep_item *items, int n, int n_trial, int n_round, int n_threads)
+{
+    if (!items || n < 0) return 1;
+    sweep_shared S;
+    S.items = items;
+    S.n = n;
+    S.n_trial = n_trial;
+    S.n_round = n_round;
+    S.next = 0;
+    pthread_mutex_init(&S.mu, NULL);
+    int nt = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+    if (nt > n) nt = n > 0 ? n : 1;
+    pthread_t th[64];
+    int started = 0;
+    for (int i = 1; i < nt; i++)
+        if (pthread_create(&th[started], NULL, sweep_worker, &S) == 0) started++;
+    sweep_worker(&S);
+    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    pthread_mutex_destroy(&S.mu);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ whole-batch plan, threaded over UTRs */
 typedef struct {
     const struct scape_host_plan_args *A;

@@ -268,15 +268,27 @@ class _Sweep:
         self.n_jobs += len(jobs)
         return jobs
 
-    def make_packed(self):
-        """make_jobs as padded tables (one native call per sweep, engine._drive's fast path)."""
+    def make_packed(self, tables=None):
+        """make_jobs as padded tables (one native call per sweep, engine._drive's fast path); `tables` = the
+        sweep tables when they were drawn together with other streams' (make_packed_many)."""
         q = self.prep
         if self.stage == "sweep" and hasattr(self.sampler, "sweep"):
-            jk, a, b, w, ka = self.sampler.sweep(q, self.n_max, self.n_min)
+            jk, a, b, w, ka = tables if tables is not None else self.sampler.sweep(q, self.n_max, self.n_min)
             n = len(jk)
             self.n_jobs += n
             return PackedJobs(np.full(n, self.u, np.int32), jk, np.zeros(n, np.int32), a, b, w, ka)
         return pack_jobs(self.make_jobs())
+
+    @staticmethod
+    def make_packed_many(sweeps):
+        """make_packed for the heads of several streams: the sweep tables of streams with distinct native samplers
+        are drawn in one threaded call (FastSampler.sweep_many)."""
+        idx = [i for i, sw in enumerate(sweeps) if sw.stage == "sweep" and isinstance(sw.sampler, FastSampler)]
+        if len(idx) < 2 or len({id(sweeps[i].sampler) for i in idx}) != len(idx):
+            return [sw.make_packed() for sw in sweeps]
+        tabs = FastSampler.sweep_many([(sweeps[i].sampler, sweeps[i].prep, sweeps[i].n_max, sweeps[i].n_min) for i in idx])
+        by = dict(zip(idx, tabs))
+        return [sw.make_packed(by.get(i)) for i, sw in enumerate(sweeps)]
 
     def absorb_packed(self, pj, out, lo, hi):
         """absorb for rows [lo, hi) of a packed EM result: only the winner becomes a Fit."""
@@ -470,7 +482,7 @@ class Engine:
             done_sweeps, deferred = [], []
             while queues:
                 heads = [q[0] for q in queues.values()]
-                packs = [sw.make_packed() for sw in heads]
+                packs = _Sweep.make_packed_many(heads)
                 pj = concat_packed(packs)
                 out = batch.em_packed(pj)
                 lo = 0
@@ -734,7 +746,7 @@ class Engine:
     def _drive(batch, sweeps, deferred=None):
         pending = list(sweeps)
         while pending and all(sw.trace is None for sw in pending):      # fast path: padded tables end to end
-            packs = [sw.make_packed() for sw in pending]
+            packs = _Sweep.make_packed_many(pending)
             pj = concat_packed(packs)
             out = batch.em_packed(pj)
             lo = 0

@@ -326,6 +326,36 @@ class FastSampler:
         return jk, a, b, w, ka
 
     @staticmethod
+    def sweep_many(reqs, n_threads=None):
+        """[(FastSampler, prep, n_max, n_min)] with pairwise distinct samplers -> [sweep tables], drawn on the host
+        threads in one native call (each sampler's stream advances exactly as in :meth:`sweep`)."""
+        if not reqs:
+            return []
+        h = reqs[0][0]._h
+        lib = reqs[0][0]._lib
+        if len({id(r[0]) for r in reqs}) != len(reqs):
+            raise ValueError("sweep_many: every request needs its own sampler")
+        items = (h.SweepItem * len(reqs))()
+        outs = []
+        for it, (smp, prep, n_max, n_min) in zip(items, reqs):
+            pk, pw, th = smp._arrays(prep)
+            n = (n_max - n_min + 1) * N_TRIAL
+            jk, a, b = np.zeros(n, np.int32), np.zeros((n, n_max), np.int32), np.zeros((n, n_max), np.int32)
+            w, ka = np.zeros((n, n_max + 1), np.float64), np.zeros((n, N_ROUND), np.int8)
+            outs.append((jk, a, b, w, ka))
+            it.state625, it.peaks, it.peak_w, it.theta = smp._sp, h.ptr(pk, h.P_d), h.ptr(pw, h.P_d), h.ptr(th, h.P_d)
+            it.n_peak, it.T, it.L, it.n_beta = len(pk), len(th), int(prep.L), len(prep.betas)
+            it.shift_scale, it.max_unif_ws = float(5 * prep.p["beta_step"]), float(prep.p["max_unif_ws"])
+            it.n_max, it.n_min, it.kmax, it.status = n_max, n_min, n_max, 1
+            it.jk, it.a, it.b, it.w, it.ka = (h.ptr(jk, h.P_i32), h.ptr(a, h.P_i32), h.ptr(b, h.P_i32), h.ptr(w, h.P_d),
+                                              h.ptr(ka, h.P_i8))
+        lib.scape_host_sweep_batch(items, len(reqs), N_TRIAL, N_ROUND, n_threads or h.host_threads())
+        for i, (it, (smp, prep, n_max, n_min)) in enumerate(zip(items, reqs)):
+            if it.status:                               # declined: this stream draws restart by restart
+                outs[i] = smp.sweep(prep, n_max, n_min)
+        return outs
+
+    @staticmethod
     def _arrays(prep):
         c = prep.__dict__.get("_native")
         if c is None:

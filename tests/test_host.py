@@ -227,6 +227,24 @@ def test_native_sweep_equals_job_by_job_draws():
         assert np.array_equal(g1[1], g2[1]) and g1[2] == g2[2]
 
 
+def test_native_sweep_many_equals_single_sweeps():
+    """The threaded batch call for the heads of several streams draws what the per-stream calls draw."""
+    from scape_amd.host import FastSampler, prepare_utr
+    from scape_amd.synth import synth_chunk
+    preps = [prepare_utr(df, g, n_max_apa=10, n_min_apa=1) for g, df in synth_chunk(7, 400, base_seed=31)]
+    one = [FastSampler(np.random.RandomState(40 + i)) for i in range(7)]
+    many = [FastSampler(np.random.RandomState(40 + i)) for i in range(7)]
+    a = [s.sweep(q, 10 - i % 3, 1 + i % 2) for i, (s, q) in enumerate(zip(one, preps))]
+    b = FastSampler.sweep_many([(s, q, 10 - i % 3, 1 + i % 2) for i, (s, q) in enumerate(zip(many, preps))], n_threads=3)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)
+    for s, t in zip(one, many):
+        assert np.array_equal(s.state, t.state)
+    with pytest.raises(ValueError):
+        FastSampler.sweep_many([(one[0], preps[0], 3, 1), (one[0], preps[1], 3, 1)])
+
+
 def test_native_plan_equals_python_plan():
     """Engine.plan (scape_host_plan, threaded) == Engine.plan_python (numpy RandomState), table for table,
     for mixed K ranges and seeds at the 32-bit edge."""
