@@ -270,11 +270,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k2_mstep (tile-stationary f64-MFMA M-step, one launch per EM round)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH, "algorithmic_bytes_per_launch": alg_bytes,
+                         "hbm_actual_gbs": PMC_TRAFFIC_BYTES_PER_LAUNCH / (m_avg_ms * 1e-3) / 1e9,
+                         "hbm_actual_frac": PMC_TRAFFIC_BYTES_PER_LAUNCH / (m_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "launch_ms": m_avg_ms, "launches_per_sweep": m_n,
                          "tensor_bytes_streamed_once": tensor_bytes,
                          "note": "algorithmic bytes = 8*N*B*|window| summed over the jobs and rounds (what a "
                                  "job-at-a-time M-step reads); the kernel streams each tensor tile once per round "
-                                 "for all jobs that need it, so achieved exceeds the HBM peak by the reuse factor",
+                                 "for all jobs that need it, so achieved exceeds the HBM peak by the reuse factor; "
+                                 "hbm_actual_* = PMC-measured bytes per launch (traffic, default workload) / launch_ms",
                          "em_sweep_ms": em_avg_ms, "em_rounds_per_sweep": int(rounds),
                          "mfma_f64_tflops": 2.0 * slab / (m_ms * 1e-3) / 1e12},
             "kernels_ms": kern,
