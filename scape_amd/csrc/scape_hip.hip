@@ -1388,7 +1388,6 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
         Np_max = std::max(Np_max, d.Np);
         W_max = std::max(W_max, max_window(th, d.T, bmax));
     }
-    if ((size_t)Np_max * sizeof(double) > 150 * 1024) return fail("n_frag too large for the LDS-resident EM kernel");
     const int64_t nb = bin_off[n_utr], nt = theta_off[n_utr];
     c->n_utr = n_utr;
     c->n_bins = nb;
@@ -1504,6 +1503,7 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     if (ev_begin(c, 2)) return 1;
     if (use_v1) {
         const size_t lds = (size_t)c->Np_max * sizeof(double);
+        if (lds > 150 * 1024) return fail("n_frag too large for the LDS-resident v1 EM kernel (use the default lock-step EM)");
 #define LAUNCH_EM(CM)                                                                                         \
     hipLaunchKernelGGL(k_em<CM>, dim3(n_jobs), dim3(EM_THREADS), lds, c->stream, c->d_desc.as<UtrDesc>(),     \
                        c->prm, c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),      \
