@@ -128,6 +128,18 @@ def end_to_end(args, pool, dev):
         dt = time.perf_counter() - t0
         assert len(written) == len(files)
         out_bytes = sum(os.path.getsize(f) for f in written)
+
+        def digests():
+            import hashlib
+            out = {}
+            for f in written:
+                h = hashlib.sha1()
+                with open(f, "rb") as fh:
+                    for blk in iter(lambda: fh.read(1 << 22), b""):
+                        h.update(blk)
+                out[os.path.basename(f)] = h.hexdigest()
+            return out
+        first = digests()
         # the same job again from pre-binned columnar chunks (scape prebin, scape_amd/binned.py)
         from scape_amd.pipeline import prebin_chunk_file
         t0 = time.perf_counter()
@@ -138,7 +150,10 @@ def end_to_end(args, pool, dev):
         infer_files(files, root, device=dev, stats=st2, rng_mode="per_utr", seed=args.base_seed,
                     re_run_mode=False, n_max_apa=args.kcap, n_min_apa=1)
         dt2 = time.perf_counter() - t0
-        prebinned = dict(value=args.e2e_utrs / dt2, seconds=dt2, prebin_s=t_prebin,
+        # full-size property: same seeds -> byte-identical result files, whatever the input form, batching and
+        # thread interleaving of the run
+        same = digests() == first
+        prebinned = dict(value=args.e2e_utrs / dt2, seconds=dt2, prebin_s=t_prebin, outputs_identical_to_pickle_run=same,
                          binned_bytes=sum(os.path.getsize(f) for f in bfiles),
                          stages_s={k: round(v, 3) for k, v in st2.items() if k.endswith("_s")})
         # and in the CLI's default mode: every chunk file keeps the reference's own random stream (results equal

@@ -186,11 +186,14 @@ def infer_files(files, output_dir, device=None, files_in_flight=128, workers=Non
                      stats=stats)             # two engines share the device (pipeline.run_pipeline)
         return written
     engine = Engine(device=device)
-    # groups of chunk files share launches; at least three groups (when there are enough files) so that the prep
-    # of the next group and the writing of the previous one overlap the GPU work of the current one
+    # groups of chunk files share launches.  Group sizes double from 16 up to files_in_flight, so the GPU starts
+    # after a short prep and the prep of each (larger) group hides behind the GPU work of the one before it
     from concurrent.futures import ThreadPoolExecutor
-    per_group = min(files_in_flight, max(16, -(-len(tasks) // 3)))
-    groups = [tasks[i:i + per_group] for i in range(0, len(tasks), per_group)]
+    groups, i, size = [], 0, min(16, files_in_flight)
+    while i < len(tasks):
+        groups.append(tasks[i:i + size])
+        i += size
+        size = min(files_in_flight, size * 2)
     pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[0]] if groups else []
     with ThreadPoolExecutor(1) as writer:
         writes = []
