@@ -186,14 +186,11 @@ def infer_files(files, output_dir, device=None, files_in_flight=128, workers=Non
                      stats=stats)             # two engines share the device (pipeline.run_pipeline)
         return written
     engine = Engine(device=device)
-    # groups of chunk files share launches.  Group sizes double from 16 up to files_in_flight, so the GPU starts
-    # after a short prep and the prep of each (larger) group hides behind the GPU work of the one before it
+    # groups of chunk files share launches: a first group of about a quarter of the files (short prep before the
+    # GPU starts), then groups of files_in_flight whose prep hides behind the GPU work of the group before
     from concurrent.futures import ThreadPoolExecutor
-    groups, i, size = [], 0, min(16, files_in_flight)
-    while i < len(tasks):
-        groups.append(tasks[i:i + size])
-        i += size
-        size = min(files_in_flight, size * 2)
+    first = min(files_in_flight, max(16, len(tasks) // 4))
+    groups = [tasks[:first]] + [tasks[i:i + files_in_flight] for i in range(first, len(tasks), files_in_flight)]
     pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[0]] if groups else []
     with ThreadPoolExecutor(1) as writer:
         writes = []
