@@ -503,6 +503,43 @@ def test_infer_pa_all_equals_per_file_runs(tmp_path):
             assert np.array_equal(a.lb_arr, b.lb_arr)
 
 
+def test_infer_files_reference_groups_equal_single_file_runs(tmp_path):
+    """More chunk files than the first group holds (16): files of different groups, waves and stream positions
+    still get exactly the result of running each file on its own."""
+    from scape_amd.apa_core import infer, infer_files
+    from scape_amd.synth import synth_chunk
+    out = tmp_path / "o"
+    (out / "pkl_input").mkdir(parents=True)
+    kw = dict(n_max_apa=2, n_min_apa=1, re_run_mode=True)
+    files = []
+    for fi in range(21):
+        f = out / "pkl_input" / f"q{fi:02d}.100.21.{fi + 1}.input.pkl"
+        with open(f, "wb") as fh:
+            for g, df in synth_chunk(1 + fi % 3, 180 + 10 * (fi % 4), k_cap=2, base_seed=2000 + fi, pa_rate=0.05):
+                pickle.dump((g, df), fh)
+        files.append(str(f))
+    written = infer_files(files, str(out), files_in_flight=4, **kw)
+    assert len(written) == 21
+
+    def load(p):
+        res = []
+        with open(p, "rb") as fh:
+            while True:
+                try:
+                    res.append(pickle.load(fh))
+                except EOFError:
+                    return res
+    for f, w in zip(files, written):
+        assert os.path.basename(w) == os.path.basename(f)[:-10] + ".res.pkl"
+        alone = infer(f, str(tmp_path / "alone.res.pkl"), **kw)
+        got = load(w)
+        assert len(got) == len(alone) > 0
+        for a, b in zip(got, alone):
+            assert a.gene_info_str == b.gene_info_str and a.K == b.K and a.bic == b.bic
+            assert np.array_equal(a.alpha_arr, b.alpha_arr) and np.array_equal(a.ws, b.ws)
+            assert np.array_equal(a.label_arr, b.label_arr) and np.array_equal(a.lb_arr, b.lb_arr)
+
+
 def test_infer_pa_all_two_worker_processes(tmp_path):
     """--gpus 2: chunk files sharded over two worker processes (each with its own prep pool and library handle;
     on a one-GPU box both use device 0).  Every file's result equals the single-process run."""
