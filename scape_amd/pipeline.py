@@ -133,6 +133,7 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
     err = []
     st = stats if stats is not None else {}
     st.update(prep_wait_s=0.0, plan_s=0.0, gpu_s=0.0, gpu_idle_s=0.0, sink_s=0.0, n_utr=0, n_batch=0)
+    abort = threading.Event()                        # set when the sink fails: stop feeding / skip queued batches
     waiting = [0]                                    # GPU threads blocked on an empty queue
     sweep_lock = threading.Lock()
     # the GPU threads re-take the GIL after every C-ABI call; with two busy Python threads beside them the
@@ -163,12 +164,12 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
             while nxt < n_task and len(futs) < ahead:
                 futs.append((nxt, pool.ex.submit(prep_fn, tasks[nxt])))
                 nxt += 1
-            while futs:
+            while futs and not abort.is_set():
                 ti, fu = futs.popleft()
                 t0 = perf_counter()
                 preps = fu.result()
                 st["prep_wait_s"] += perf_counter() - t0
-                if nxt < n_task:
+                if nxt < n_task and not abort.is_set():
                     futs.append((nxt, pool.ex.submit(prep_fn, tasks[nxt])))
                     nxt += 1
                 sizes[ti] = len(preps)
@@ -178,7 +179,10 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
                     meta.append((ti, j, (seed + j) % (2 ** 32)))
                     if len(cur) >= batch_utrs or (len(cur) >= min_batch_utrs and waiting[0] and q_gpu.empty()):
                         flush()
-            flush()
+            for _ti, fu in futs:                      # aborted: nothing more is wanted from the workers
+                fu.cancel()
+            if not abort.is_set():
+                flush()
         except BaseException as e:                    # noqa: BLE001 - handed to the caller's thread
             err.append(e)
         finally:
@@ -198,6 +202,8 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
                 if item is _STOP:
                     break
                 preps, meta, plan = item
+                if abort.is_set():
+                    continue
                 t0 = perf_counter()
                 if plan is None:
                     res = eng.run(preps, rng_mode="per_utr", seeds=[m[2] for m in meta], re_run_mode=re_run_mode)
@@ -250,9 +256,13 @@ def run_pipeline(tasks, prep_fn, sink, engine_factory, pool, *, seed=1, re_run_m
                 done[ti][j] = UtrResult(prep=q, fit=fit, labels_bin=lab, n_jobs=nj)
             n_utr += len(preps)
         t0 = perf_counter()
-        while next_task in sizes and all(r is not None for r in done[next_task]):
-            sink(next_task, done.pop(next_task))
-            next_task += 1
+        try:
+            while not err and next_task in sizes and all(r is not None for r in done[next_task]):
+                sink(next_task, done.pop(next_task))
+                next_task += 1
+        except BaseException as e:                    # noqa: BLE001 - a failing sink stops the other stages too
+            err.append(e)
+            abort.set()
         st["sink_s"] += perf_counter() - t0
     tp.join()
     for tg in tgs:

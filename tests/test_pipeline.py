@@ -81,6 +81,11 @@ def test_pipeline_propagates_worker_and_gpu_errors(tmp_path, pool):
         pipeline.run_pipeline([(files[0], kw), (os.path.join(str(tmp_path), "missing.input.pkl"), kw)],
                               pipeline.prep_chunk_file, lambda ti, res: None, FakeEngine, pool, batch_utrs=2)
 
+    def bad_sink(ti, res):
+        raise OSError("disk full")
+    with pytest.raises(OSError, match="disk full"):
+        pipeline.run_pipeline([(f, kw) for f in files], pipeline.prep_chunk_file, bad_sink, FakeEngine, pool, batch_utrs=2)
+
     class Boom(FakeEngine):
         def process(self, *a):
             raise RuntimeError("device lost")
