@@ -785,14 +785,23 @@ struct DevBuf {
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap && p) return 0;
+        // a buffer that has to grow gets 1/8 headroom: successive batches of a stream differ by a few per cent in
+        // size, and re-allocating tens of GB for each of them costs more than the batch itself
+        const bool regrow = p != nullptr;
         if (p) {
             (void)hipFree(p);
             p = nullptr;
             cap = 0;
         }
         if (bytes == 0) bytes = 16;
-        HIPCHK(hipMalloc(&p, bytes));
-        cap = bytes;
+        size_t want = regrow ? bytes + bytes / 8 : bytes;
+        if (hipMalloc(&p, want) != hipSuccess) {     // no room for the headroom: exact size
+            (void)hipGetLastError();
+            p = nullptr;
+            want = bytes;
+            HIPCHK(hipMalloc(&p, want));
+        }
+        cap = want;
         return 0;
     }
     void release() {
