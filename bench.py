@@ -101,6 +101,32 @@ def cpu_baseline(preps, plan, target_s, cores):
                        f"on {cores} threads, {dt:.1f} s wall; 1 UTR on 1 thread = {t1:.2f} s"), [first] + outs
 
 
+def parity_count(preps, plan, res, outs):
+    """How many of the UTRs the CPU port ran (`outs` of cpu_baseline) got the same pA calls from the GPU step
+    (`res` of Engine.process): the port's jobs go through the reference's selection (float32 BIC arg-mins,
+    apa_core.py:849/:865/:945/:972) and pruning rule (:832-844) and are compared with the GPU's final fit."""
+    same = 0
+    for u, alpha, beta, ws, bic, nlb in outs:
+        lo = int(plan["spans"][u])
+        grid = bic.astype(np.float32).reshape(-1, 10)      # the reference's bic_arr is float32
+        tb = np.argmin(grid, axis=1)
+        kb = int(np.argmin(grid[np.arange(len(tb)), tb]))
+        j = kb * 10 + int(tb[kb])
+        K = int(plan["main"].jk[lo + j])
+        fit = res[u][0]
+        q = preps[u]
+        pruned = bool(np.any(ws[j, :K] < q.p["min_ws"]))
+        if pruned:
+            keep = ~(ws[j, :K] < q.p["min_ws"])
+            same += (fit.K == int(keep.sum()) and np.array_equal(q.theta[fit.a_idx], alpha[j, :K][keep])
+                     and np.array_equal(q.betas[fit.b_idx], beta[j, :K][keep]))
+        else:
+            same += (fit.K == K and np.array_equal(q.theta[fit.a_idx], alpha[j, :K])
+                     and np.array_equal(q.betas[fit.b_idx], beta[j, :K])
+                     and np.allclose(fit.ws, ws[j, :K + 1], rtol=1e-4, atol=1e-9))
+    return int(same)
+
+
 def end_to_end(args, pool, dev):
     """The whole `infer_pa` job as a user runs it, on a bounded sample of the same synthetic stream:
     prepare_input-style chunk files on disk -> non-executing unpickle -> binning / coverage peaks (process
@@ -304,26 +330,7 @@ def main():
             cores = min(16, os.cpu_count() or 1)
             cb, outs = cpu_baseline(preps, plan, args.cpu_seconds, cores)
             out["cpu_baseline"] = cb
-            # parity of the sampled UTRs' winners (GPU step result vs the oracle's jobs + same selection)
-            same = 0
-            for u, alpha, beta, ws, bic, nlb in outs:
-                lo = int(plan["spans"][u])
-                grid = bic.astype(np.float32).reshape(-1, 10)      # the reference's bic_arr is float32
-                tb = np.argmin(grid, axis=1)
-                kb = int(np.argmin(grid[np.arange(len(tb)), tb]))
-                j = kb * 10 + int(tb[kb])
-                K = int(plan["main"].jk[lo + j])
-                fit = res[u][0]
-                q = preps[u]
-                pruned = bool(np.any(ws[j, :K] < q.p["min_ws"]))
-                if pruned:
-                    keep = ~(ws[j, :K] < q.p["min_ws"])
-                    same += (fit.K == int(keep.sum()) and np.array_equal(q.theta[fit.a_idx], alpha[j, :K][keep])
-                             and np.array_equal(q.betas[fit.b_idx], beta[j, :K][keep]))
-                else:
-                    same += (fit.K == K and np.array_equal(q.theta[fit.a_idx], alpha[j, :K])
-                             and np.array_equal(q.betas[fit.b_idx], beta[j, :K])
-                             and np.allclose(fit.ws, ws[j, :K + 1], rtol=1e-4, atol=1e-9))
+            same = parity_count(preps, plan, res, outs)
             out["cpu_baseline"]["parity_sample"] = f"{same}/{len(outs)} sampled UTRs: GPU pA calls identical to the CPU port"
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / cb["value"]
         if pool is not None:

@@ -503,6 +503,32 @@ def test_infer_pa_all_equals_per_file_runs(tmp_path):
             assert np.array_equal(a.lb_arr, b.lb_arr)
 
 
+def test_config2_full_size_every_utr_vs_cpu_port(oracle):
+    """BASELINE config #2 at its full size: 1,000 UTRs x 500 reads, K = 1..5 x 10 restarts (50,000 EM jobs).
+    One resident GPU batch; the CPU port (oracle) runs the same 50 jobs of EVERY UTR on the host threads and goes
+    through the reference's selection and pruning rule; all 1,000 pA calls must agree (K, alpha, beta; ws to 1e-4
+    where no re-fit is involved - the bench's own parity check)."""
+    import bench
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    U, kw = 1000, dict(n_max_apa=5, n_min_apa=1)
+    preps = []
+    for i in range(U):
+        g, df, _ = synth_utr(i, 500, k_cap=5, base_seed=777)
+        preps.append(prepare_utr(df, gene_info_str=g, **kw))
+    eng = Engine()
+    plan = eng.plan(preps, [(777 + i) % 2 ** 32 for i in range(U)])
+    assert len(plan["main"]) == 50 * U
+    res = eng.process(eng.load(preps), preps, plan, re_run_mode=False)
+    cores = min(16, os.cpu_count() or 1)
+    cb, outs = bench.cpu_baseline(preps, plan, 1e9, cores)          # target time = infinity: every UTR
+    assert len(outs) == U
+    assert bench.parity_count(preps, plan, res, outs) == U
+    for (fit, lab, nj), q in zip(res, preps):
+        assert 1 <= fit.K <= 5 and len(lab) == q.N and abs(fit.ws.sum() - 1) < 1e-12
+
+
 def test_infer_files_reference_groups_equal_single_file_runs(tmp_path):
     """More chunk files than the first group holds (16): files of different groups, waves and stream positions
     still get exactly the result of running each file on its own."""
