@@ -40,6 +40,7 @@ def _worker_init(owner_pid):
             except OSError:
                 os._exit(0)
     threading.Thread(target=watch, name="scape-owner-watch", daemon=True).start()
+    from . import apa_core, binned  # noqa: F401  (numpy / pandas / scipy imported now, not inside the first task)
 
 
 def prep_chunk_file(args):
