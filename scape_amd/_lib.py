@@ -13,7 +13,7 @@ import numpy as np
 SENT = float(np.finfo("f").min)   # reference taichi_core.py:8 / apa_core.py:428
 MAX_BETA, MAX_S, MAX_K = 64, 64, 31
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscape_hip.so")
+LIB_PATH = os.environ.get("SCAPE_HIP_LIB") or os.path.join(_HERE, "libscape_hip.so")   # override: A/B builds only
 
 c_d, c_i, c_i32, c_i64 = ctypes.c_double, ctypes.c_int, ctypes.c_int32, ctypes.c_int64
 P_d = ctypes.POINTER(c_d)
