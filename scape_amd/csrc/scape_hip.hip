@@ -1109,7 +1109,10 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             if (r < nround && any_m) {
                 if (fine && ev_begin(c, 5)) return 1;
                 const int nu = g_a0[g + 1] - g_a0[g];
-                hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max)), dim3(256), 0, st,
+                // few active UTRs: the GPU is mostly idle and a round's time is one workgroup's serial time, so the
+                // two 64-job passes of a tile with up to 128 jobs go to two workgroups
+                const unsigned psplit = (nu <= 64 && n_jobs / std::max(nu, 1) > MT_MAXJ) ? 2u : 1u;
+                hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max), psplit), dim3(256), 0, st,
                                    c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, tiles_max,
                                    c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo,
                                    S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row,
