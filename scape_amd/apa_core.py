@@ -159,9 +159,11 @@ def _infer_pa(pkl_input_file: str, output_dir: str, **kwargs):
 
 def _write_results(output_dir, pkl_input_file, results):
     out = os.path.join(output_dir, "pkl_output", os.path.basename(pkl_input_file)[:-10] + ".res.pkl")
-    with open(out, "wb") as fh:
+    tmp = out + ".part"                                  # complete files only ever appear under the final name
+    with open(tmp, "wb") as fh:
         for r in results:
             pickle.dump(to_parameters(r), fh)
+    os.replace(tmp, out)
     return out
 
 
@@ -216,10 +218,12 @@ def _infer_files_worker(rank, files, output_dir, kwargs, workers):
         close_shared_pool()                                # or this process never gets past its exit join
 
 
-def infer_all(output_dir, gpus=1, **kwargs):
+def infer_all(output_dir, gpus=1, resume=False, **kwargs):
     """Every complete chunk of <output_dir>/pkl_input on `gpus` GPUs of this node: chunk files are sharded
     over one worker process per GPU (largest-first by file size), no communication between workers
-    (merge_pa expects one .res.pkl per .input.pkl, reference junction_handler.py:59-64)."""
+    (merge_pa expects one .res.pkl per .input.pkl, reference junction_handler.py:59-64).
+    resume: leave out the chunks whose .res.pkl already exists and is not older than the chunk (result files
+    are written under a temporary name and renamed, so an existing one is complete)."""
     import glob
     import multiprocessing as mp
 
@@ -228,6 +232,15 @@ def infer_all(output_dir, gpus=1, **kwargs):
                    if ".tmp." not in os.path.basename(f))
     if not files:
         raise Exception("no *.input.pkl under " + os.path.join(output_dir, "pkl_input"))
+    if resume:
+        def done(f):
+            out = os.path.join(output_dir, "pkl_output", os.path.basename(f)[:-10] + ".res.pkl")
+            return os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(f)
+        todo = [f for f in files if not done(f)]
+        print(f"resume: {len(files) - len(todo)} of {len(files)} chunks already have results")
+        files = todo
+        if not files:
+            return []
     shards = lpt_partition([os.path.getsize(f) for f in files], gpus)
     if gpus == 1:
         infer_files(files, output_dir, device=kwargs.pop("device", None), **kwargs)
@@ -258,7 +271,9 @@ def infer_all(output_dir, gpus=1, **kwargs):
               required=True)
 @click.option('--toml_para_file', type=str, default=None, required=False)
 @click.option('--gpus', type=int, default=1, help='number of GPUs of this node to shard the chunk files over')
-def infer_pa_all(output_dir: str, toml_para_file: str = None, gpus: int = 1):
+@click.option('--resume', is_flag=True, default=False,
+              help='skip the chunks whose .res.pkl already exists and is not older than the chunk')
+def infer_pa_all(output_dir: str, toml_para_file: str = None, gpus: int = 1, resume: bool = False):
     """infer_pa for every chunk under <output_dir>/pkl_input (not in the reference CLI: its tutorial
     loops `scape infer_pa` over the files in a shell, SCAPE-example-with-DE.ipynb cell 8)."""
     assert Path(output_dir).exists()
@@ -269,7 +284,7 @@ def infer_pa_all(output_dir: str, toml_para_file: str = None, gpus: int = 1):
     with open(toml_para_file, "rb") as fh:
         para_dict.update(_toml.load(fh))
     para_dict.pop("output_dir", None)
-    infer_all(output_dir, gpus=gpus, **para_dict)
+    infer_all(output_dir, gpus=gpus, resume=resume, **para_dict)
 
 
 @click.command(name="prebin")

@@ -345,6 +345,25 @@ def test_cli_error_behaviour(tmp_path):
     assert isinstance(r.exception, AssertionError)
 
 
+def test_infer_all_resume_skips_finished_chunks(tmp_path, monkeypatch):
+    from scape_amd import apa_core
+    d = tmp_path / "o"
+    (d / "pkl_input").mkdir(parents=True)
+    (d / "pkl_output").mkdir()
+    for i in range(4):
+        (d / "pkl_input" / f"c.100.4.{i + 1}.input.pkl").write_bytes(b"x")
+    (d / "pkl_input" / "c.tmp.100.4.9.input.pkl").write_bytes(b"x")          # incomplete chunk: never processed
+    (d / "pkl_output" / "c.100.4.2.res.pkl").write_bytes(b"y")                 # finished
+    (d / "pkl_output" / "c.100.4.3.res.pkl").write_bytes(b"y")                 # older than its chunk -> redo
+    os.utime(d / "pkl_output" / "c.100.4.3.res.pkl", (1, 1))
+    seen = []
+    monkeypatch.setattr(apa_core, "infer_files", lambda files, out, **kw: seen.append([os.path.basename(f) for f in files]))
+    apa_core.infer_all(str(d), gpus=1, resume=True, n_max_apa=3)
+    assert seen == [["c.100.4.1.input.pkl", "c.100.4.3.input.pkl", "c.100.4.4.input.pkl"]]
+    apa_core.infer_all(str(d), gpus=1, n_max_apa=3)
+    assert len(seen[1]) == 4
+
+
 def test_wave_split_respects_budget(monkeypatch):
     from scape_amd import engine
 
