@@ -819,6 +819,7 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
+#define N_COUNTERS (4 + 2 * 64)   // rounds, slab elements (v1), z elements, unused, then 64 + 64 shards (em_lockstep.inc)
 struct scape_hip_ctx {
     int device = 0;
     std::atomic<bool> busy{false};   // a handle serves one host thread at a time (scape_hip.h)
@@ -1123,11 +1124,12 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         }
         if (r < nround && (r & 3) == 3) {
             // early exit: no job executed a round since the last probe -> every job has been finalised
-            unsigned long long executed = 0;
+            unsigned long long executed = 0, shard[64];
             if (split) HIPCHK(hipStreamSynchronize(c->stream2));
-            HIPCHK(hipMemcpyAsync(&executed, c->d_counters.as<unsigned long long>() + 3, sizeof(executed),
+            HIPCHK(hipMemcpyAsync(shard, c->d_counters.as<unsigned long long>() + 4 + 64, sizeof(shard),
                                   hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < 64; ++i) executed += shard[i];
             if (executed == executed_prev) break;
             executed_prev = executed;
         }
@@ -1175,7 +1177,7 @@ int scape_hip_create(int device, scape_hip_ctx **out) {
     snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipStreamCreate(&c->stream2));
-    if (c->d_counters.ensure(4 * sizeof(unsigned long long))) return 1;
+    if (c->d_counters.ensure(N_COUNTERS * sizeof(unsigned long long))) return 1;
     *out = c;
     return 0;
 }
@@ -1508,7 +1510,7 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipMemcpyAsync(c->j_b.p, beta_idx, nj * kmax * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->j_ws.p, ws, nj * (kmax + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->j_karr.p, k_arr, nj * nround, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters.p, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->j_lb.p, 0, nj * nround * 8, c->stream));
     const char *mode = getenv("SCAPE_HIP_EM");
     const bool use_v1 = mode && strcmp(mode, "v1") == 0;
@@ -1539,8 +1541,11 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipMemcpyAsync(bic_out, c->j_bic.p, nj * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(n_lb_out, c->j_nlb.p, nj * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(lb_out, c->j_lb.p, nj * nround * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_counters, c->d_counters.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long hc[N_COUNTERS];
+    HIPCHK(hipMemcpyAsync(hc, c->d_counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; ++i) c->h_counters[i] = hc[i];
+    for (int i = 0; i < 64; ++i) c->h_counters[1] += hc[4 + i];   // sharded slab-element counter of the lock-step EM
     return 0;
 }
 
