@@ -225,51 +225,118 @@ def _load_results(path):
     return out
 
 
-def _merge_pa(output_dir: str, utr_merge=True):
+def _key_of(gene_info_str, utr_merge):
+    parts = gene_info_str.split(":")
+    return parts[1] if utr_merge else ":".join(parts[1:3])
+
+
+def _input_stream(path):
+    """(gene_info_str, columns) of one input chunk: from its columnar copy when that is current, else the pickle"""
+    from .binned import binned_path, is_current, read_binned
+    if is_current(binned_path(path), path):
+        return ((g, cols) for g, _b, cols in read_binned(binned_path(path)))
+    return read_input_chunk(path)
+
+
+def _merge_keys_task(args):
+    """Worker: the gene keys of one result file, in order of first appearance."""
+    path, utr_merge = args
+    seen = {}
+    for para in _load_results(path):
+        seen.setdefault(_key_of(para.gene_info_str, utr_merge), None)
+    return list(seen)
+
+
+def _merge_file_task(args):
+    """Worker: merge the genes that first appear in one chunk (their records may continue in other chunks, which
+    are loaded too) and write them, in order, to a part file.  Returns the number of genes written."""
+    output_dir, stems, genes, utr_merge, part_path = args
+    wanted = set(genes)
+    res_by_gene, in_by_gene = {g: {} for g in genes}, {g: {} for g in genes}
+    for stem in stems:                                  # sorted file order = the serial path's insertion order
+        for para in _load_results(os.path.join(output_dir, "pkl_output", stem + ".res.pkl")):
+            k = _key_of(para.gene_info_str, utr_merge)
+            if k in wanted:
+                res_by_gene[k][para.gene_info_str] = para
+        for gene_info_str, df in _input_stream(os.path.join(output_dir, "pkl_input", stem + ".input.pkl")):
+            k = _key_of(gene_info_str, utr_merge)
+            if k in wanted:
+                in_by_gene[k][gene_info_str] = df
+    with open(part_path, "wb") as fh:
+        for g in genes:
+            para, _junc, _change = merge_gene(in_by_gene[g], res_by_gene[g], g)
+            pickle.dump(para, fh)
+    return len(genes)
+
+
+def _merge_pa(output_dir: str, utr_merge=True, workers=None):
+    """Returns the number of merged records written.  workers: None = the shared prep pool (parallel over chunk
+    files when there are at least four), 0 = in this process."""
     if not os.path.exists(os.path.join(output_dir, "pkl_output")):
         raise Exception("Please use the same directory that stores res pickle files by infer_pa")
     if not os.path.exists(os.path.join(output_dir, "pkl_input")):
         raise Exception("Please use the same directory that stores res pickle files by prepare_input")
     in_files = sorted(f for f in os.listdir(os.path.join(output_dir, "pkl_input")) if ".input.pkl" in f)
     out_files = sorted(f for f in os.listdir(os.path.join(output_dir, "pkl_output"))
-                       if ".res.pkl" in f and f[:-8] + ".input.pkl" in in_files)
+                       if f.endswith(".res.pkl") and f[:-8] + ".input.pkl" in in_files)
     if len(in_files) != len(out_files):
         raise Exception("Number of *.res.pkl is different from number of *.input.pkl. Please make sure that all "
                         "input files are successfully used for infering PAS.")
     outfile = os.path.join(output_dir, "res.gene.pkl" if utr_merge else "res.utr.pkl")
-
-    def key_of(gene_info_str):
-        parts = gene_info_str.split(":")
-        return parts[1] if utr_merge else ":".join(parts[1:3])
-
-    res_by_gene, in_by_gene = {}, {}
-    for f in out_files:
-        for para in _load_results(os.path.join(output_dir, "pkl_output", f)):
-            res_by_gene.setdefault(key_of(para.gene_info_str), {})[para.gene_info_str] = para
-    print("Done read model output_dir")
-    from .binned import binned_path, is_current, read_binned
-    for f in in_files:
-        path = os.path.join(output_dir, "pkl_input", f)
-        if is_current(binned_path(path), path):        # columnar copy of the chunk: no pickle decoding
-            stream = ((g, cols) for g, _b, cols in read_binned(binned_path(path)))
-        else:
-            stream = read_input_chunk(path)
-        for gene_info_str, df in stream:
-            in_by_gene.setdefault(key_of(gene_info_str), {})[gene_info_str] = df
-    print("Done read model input")
     st = timer()
     try:
         os.remove(outfile)
     except OSError:
         pass
-    merged = []
-    with open(outfile, "wb") as fh:
-        for gene, results in res_by_gene.items():
-            para, _junc, _change = merge_gene(in_by_gene[gene], results, gene)
-            pickle.dump(para, fh)
-            merged.append(para)
+    stems = [f[:-8] for f in out_files]
+    if workers == 0 or len(stems) < 4:
+        n = _merge_file_task((output_dir, stems, _all_keys(output_dir, stems, utr_merge), utr_merge, outfile))
+        print("Done read model output_dir")
+        print("Done read model input")
+        print(timer() - st)
+        return n
+    # parallel over chunk files: every gene belongs to the chunk it first appears in (file order, record order - the
+    # order the serial path writes them in); the part files are concatenated in chunk order
+    from .pipeline import shared_pool
+    pool = shared_pool(workers)
+    keys = list(pool.ex.map(_merge_keys_task, [(os.path.join(output_dir, "pkl_output", s + ".res.pkl"), utr_merge)
+                                               for s in stems]))
+    print("Done read model output_dir")
+    first, files_of = {}, {}
+    for i, ks in enumerate(keys):
+        for k in ks:
+            first.setdefault(k, i)
+            files_of.setdefault(k, []).append(i)
+    tasks, parts = [], []
+    for i, ks in enumerate(keys):
+        genes = [k for k in ks if first[k] == i]
+        if not genes:
+            continue
+        need = sorted({j for k in genes for j in files_of[k]} | {i})
+        parts.append(outfile + f".part{i}")
+        tasks.append((output_dir, [stems[j] for j in need], genes, utr_merge, parts[-1]))
+    print("Done read model input")
+    counts = list(pool.ex.map(_merge_file_task, tasks))
+    with open(outfile + ".part", "wb") as fh:
+        for part in parts:
+            with open(part, "rb") as src:
+                while True:
+                    blk = src.read(1 << 24)
+                    if not blk:
+                        break
+                    fh.write(blk)
+            os.remove(part)
+    os.replace(outfile + ".part", outfile)
     print(timer() - st)
-    return merged
+    return int(sum(counts))
+
+
+def _all_keys(output_dir, stems, utr_merge):
+    seen = {}
+    for stem in stems:
+        for k in _merge_keys_task((os.path.join(output_dir, "pkl_output", stem + ".res.pkl"), utr_merge)):
+            seen.setdefault(k, None)
+    return list(seen)
 
 
 @click.command(name="merge_pa")
@@ -278,7 +345,9 @@ def _merge_pa(output_dir: str, utr_merge=True):
 @click.option('--utr_merge', type=bool, default=True,
               help='By default, True if want to process all pa site of one gene at together. False if want to process '
                    'each utr_file separately.')
-def merge_pa(output_dir: str, utr_merge=True):
+@click.option('--workers', type=int, default=None,
+              help='processes to spread the chunk files over (default: one per host core, at most 14; 0 = none)')
+def merge_pa(output_dir: str, utr_merge=True, workers=None):
     """Merge junction-artefact pA sites per gene and write res.gene.pkl / res.utr.pkl
     (reference junction_handler.py:28-42)."""
-    _merge_pa(output_dir, utr_merge)
+    _merge_pa(output_dir, utr_merge, workers=workers)

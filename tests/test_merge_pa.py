@@ -136,3 +136,45 @@ def test_merge_pa_cli_on_own_directory(tmp_path):
     os.remove(out / "pkl_output" / "s.100.2.2.res.pkl")
     r = CliRunner().invoke(cli, ["merge_pa", "--output_dir", str(out)])
     assert r.exit_code != 0 and "Number of *.res.pkl" in str(r.exception)
+
+
+def test_parallel_merge_over_chunk_files_equals_serial(tmp_path):
+    """Six chunk files, the records of multi-record genes spread over different files (a gene belongs to the chunk
+    it first appears in, later chunks are loaded for its other records): the worker-pool path writes the same
+    bytes as the in-process path."""
+    from scape_amd.apa_core import Parameters
+    from scape_amd.junction_handler import _merge_pa
+    f = load_npz("trace_merge_syn.npz")
+    out = tmp_path / "o"
+    (out / "pkl_input").mkdir(parents=True)
+    (out / "pkl_output").mkdir()
+    cases = [c for c in range(int(f["n_case"])) if ":" not in str(f[f"c{c}_key"])
+             and all(int(f[f"c{c}_r{j}_K"]) > 0 for j in range(int(f[f"c{c}_n_rec"])))][:40]
+    F = 6
+    fin = [open(out / "pkl_input" / f"s.100.{F}.{i + 1}.input.pkl", "wb") for i in range(F)]
+    fres = [open(out / "pkl_output" / f"s.100.{F}.{i + 1}.res.pkl", "wb") for i in range(F)]
+    n_multi = 0
+    for ci, c in enumerate(cases):
+        pre = f"c{c}_"
+        ins, res = _records(f, pre, int(f[pre + "n_rec"]))
+        n_multi += len(res) > 1
+        for j, (g, r_) in enumerate(res.items()):
+            k = (ci + 2 * j) % F                      # records of one gene land in different chunk files
+            n = len(ins[g])
+            df = pd.DataFrame({"x": np.zeros(n, int), "l": 50, "r": np.nan, "pa": np.nan, "cb_id": 0,
+                               "read_id": ins[g]["read_id"], "junction": ins[g]["junction"],
+                               "seg1_en": ins[g]["seg1_en"], "seg2_en": ins[g]["seg2_en"]})
+            pickle.dump((g, df), fin[k])
+            p = Parameters(title="Final Result", alpha_arr=r_.alpha_arr, beta_arr=r_.beta_arr,
+                           ws=np.full(r_.K + 1, 1 / (r_.K + 1)), L=2000, cb_id_arr=r_.cb_id_arr, readID_arr=r_.readID_arr)
+            p.label_arr, p.gene_info_str = r_.label_arr, g
+            pickle.dump(p, fres[k])
+    for fh in fin + fres:
+        fh.close()
+    assert n_multi >= 5
+    for mode, name in ((True, "res.gene.pkl"), (False, "res.utr.pkl")):
+        n0 = _merge_pa(str(out), mode, workers=0)
+        serial = open(out / name, "rb").read()
+        n1 = _merge_pa(str(out), mode, workers=2)
+        assert n0 == n1 > 0 and open(out / name, "rb").read() == serial
+        assert not [p for p in os.listdir(out) if ".part" in p]
