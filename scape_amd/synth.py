@@ -44,9 +44,16 @@ def synth_utr(index, n_reads, k_cap=5, base_seed=0, pa_rate=0.015, noise=0.05, r
     if r_rate > 0:
         has_r = (rng.random(n_reads) < r_rate) & ~has_pa & ~is_noise
         r[has_r] = np.minimum(np.floor(rng.random(int(has_r.sum())) * s[has_r]) + 1, s[has_r])
+    # the three columns merge_pa reads (input_processor.py:636): a few junction reads with their segment ends in
+    # genomic coordinates; drawn from a generator of their own, so the model columns above do not depend on them
+    jrng = np.random.default_rng([base_seed + index, 7])
+    junction = (jrng.random(n_reads) < 0.03).astype(np.int64)
+    seg1 = np.where(junction == 1, 1.0 + x + np.floor(jrng.random(n_reads) * l), np.nan)
+    seg2 = np.where(junction == 1, 1.0 + x + l, np.nan)
     df = pd.DataFrame({"x": x.astype(np.int64), "l": l.astype(np.int64), "r": r, "pa": pa,
                        "cb_id": np.arange(n_reads, dtype=np.int64),
-                       "read_id": np.arange(n_reads, dtype=np.int64)})
+                       "read_id": np.arange(n_reads, dtype=np.int64),
+                       "junction": junction, "seg1_en": seg1, "seg2_en": seg2})
     gene = f"syn:G{index:07d}:1:1-{L_true}:+"
     truth = dict(alphas=alphas, betas=betas, ws=ws, L_true=L_true)
     return gene, df, truth
