@@ -68,7 +68,7 @@ class PrepPool:
     (workers come from a fork server that never sees a HIP context)."""
 
     def __init__(self, workers=None):
-        self.workers = workers if workers else max(1, _hostlib.host_threads() - 2)
+        self.workers = workers if workers else max(1, _hostlib.host_threads() - 4)   # planner, two GPU threads, writer
         self.ex = ProcessPoolExecutor(self.workers, mp_context=mp.get_context("forkserver"),
                                       initializer=_worker_init, initargs=(os.getpid(),))
         list(self.ex.map(int, range(self.workers)))            # bring the workers up now
