@@ -10,6 +10,16 @@ resident in HBM: Phase A -> Phase B -> EM sweep -> BIC selection -> prune re-fit
 back on the host.  Binned inputs and the restart tables are uploaded / drawn before the timed region.
 With N > 1 every rank processes its own batch of the stream (weak scaling, no data-path collective);
 value = UTRs all ranks processed / max-over-ranks time.
+
+Launch: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` every rank reads
+RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Started plainly with `--gpus N` (N > 1, no WORLD_SIZE)
+this process starts the N ranks itself as fresh child processes BEFORE touching the GPU, runs the multi-GPU
+end-to-end leg, merges it into rank 0's JSON line and prints that one line; a failed rank is a non-zero exit.
+
+roofline (the dominant kernel, k2_mstep): `traffic` = HBM-side bytes per launch as tallied by the kernel
+itself (tensor-tile bytes streamed + each job's v vector once; scape_hip_em_traffic), `achieved` = traffic /
+HIP-event launch time, `frac` = achieved / 8 TB/s.  SURVEY.md 8(d)'s job-at-a-time slab bytes are kept beside
+it as `algorithmic_bytes_per_launch` with `reuse_factor` = algorithmic / traffic.
 """
 from __future__ import annotations
 
@@ -27,9 +37,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
-# HBM bytes per k2_mstep launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) at
-# the default workload (512 UTRs x 2k reads per step); see profiles/README.md.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = 11.2e9
 
 
 def parse():
@@ -42,8 +49,15 @@ def parse():
     ap.add_argument("--kcap", type=int, default=10)
     ap.add_argument("--base-seed", type=int, default=20250225)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-utrs", type=int, default=16384,
-                    help="UTRs of the untimed-by-the-metric end-to-end leg (chunk files -> .res.pkl), 0 = skip")
+    ap.add_argument("--e2e-utrs", type=int, default=50000,
+                    help="UTRs of the untimed-by-the-metric end-to-end leg (chunk files -> .res.pkl), 0 = skip; "
+                         "default = the whole headline job")
+    ap.add_argument("--e2e-ref-utrs", type=int, default=16384,
+                    help="UTRs of the end-to-end leg in the exact reference-stream mode (a prefix of the same files)")
+    ap.add_argument("--e2e-multi-utrs", type=int, default=2048,
+                    help="N > 1: UTRs PER GPU of the multi-GPU end-to-end leg (infer_all(gpus=N) on chunk files of "
+                         "BASELINE config #4's shape), 0 = skip")
+    ap.add_argument("--e2e-multi-reads", type=int, default=10000)
     ap.add_argument("--e2e-workers", type=int, default=0, help="prep processes of the end-to-end leg (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -127,25 +141,47 @@ def parity_count(preps, plan, res, outs):
     return int(same)
 
 
+def host_info():
+    """What the CPU-side numbers were measured on (printed with cpu_baseline and the end-to-end legs)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return dict(cpu_model=model, nproc=os.cpu_count() or 1, nproc_usable=usable)
+
+
+def write_synth_chunks(pool, root, n_utrs, reads, kcap, base_seed, per_file=128, first_index=10 ** 6):
+    os.makedirs(os.path.join(root, "pkl_input"), exist_ok=True)
+    from scape_amd.pipeline import synth_chunk_file
+    tasks = [(os.path.join(root, "pkl_input", f"synth.{per_file}.{i}.input.pkl"), first_index + i * per_file,
+              min(per_file, n_utrs - i * per_file), reads, kcap, base_seed)
+             for i in range((n_utrs + per_file - 1) // per_file)]
+    t0 = time.perf_counter()
+    files = list(pool.ex.map(synth_chunk_file, tasks))
+    return files, time.perf_counter() - t0
+
+
 def end_to_end(args, pool, dev):
-    """The whole `infer_pa` job as a user runs it, on a bounded sample of the same synthetic stream:
-    prepare_input-style chunk files on disk -> non-executing unpickle -> binning / coverage peaks (process
-    pool) -> restart tables (native sampler) -> GPU -> Parameters -> pkl_output/*.res.pkl.  SURVEY.md 8(d):
-    the rate WITH host pre/post-processing, reported beside `value` (which is the resident-batch rate)."""
+    """The whole `infer_pa` job as a user runs it, on the same synthetic stream (default: all 50,000 UTRs of
+    the headline job): prepare_input-style chunk files on disk -> non-executing unpickle -> binning /
+    coverage peaks (process pool) -> restart tables (native sampler) -> GPU -> Parameters ->
+    pkl_output/*.res.pkl.  SURVEY.md 8(d): the rate WITH host pre/post-processing, reported beside `value`
+    (which is the resident-batch rate)."""
     import shutil
     import tempfile
     from scape_amd.apa_core import infer_files
-    from scape_amd.pipeline import synth_chunk_file
     root = tempfile.mkdtemp(prefix="scape_e2e_")
     try:
-        os.makedirs(os.path.join(root, "pkl_input"))
-        per_file = 128
-        tasks = [(os.path.join(root, "pkl_input", f"synth.{per_file}.{i}.input.pkl"), 10 ** 6 + i * per_file,
-                  min(per_file, args.e2e_utrs - i * per_file), args.reads, args.kcap, args.base_seed)
-                 for i in range((args.e2e_utrs + per_file - 1) // per_file)]
-        t0 = time.perf_counter()
-        files = list(pool.ex.map(synth_chunk_file, tasks))
-        t_write = time.perf_counter() - t0
+        files, t_write = write_synth_chunks(pool, root, args.e2e_utrs, args.reads, args.kcap, args.base_seed)
         in_bytes = sum(os.path.getsize(f) for f in files)
         st = {}
         t0 = time.perf_counter()
@@ -183,12 +219,17 @@ def end_to_end(args, pool, dev):
                          binned_bytes=sum(os.path.getsize(f) for f in bfiles),
                          stages_s={k: round(v, 3) for k, v in st2.items() if k.endswith("_s")})
         # and in the CLI's default mode: every chunk file keeps the reference's own random stream (results equal
-        # the reference's run of that file), the files' current UTRs share the launches (Engine.run_streams)
+        # the reference's run of that file), the files' current UTRs share the launches (Engine.run_streams);
+        # re_run_mode on, as the reference's default parameter file has it (input_processor.py:97-112)
+        n_ref_files = max(1, min(len(files), (args.e2e_ref_utrs + 127) // 128))
+        ref_files = files[:n_ref_files]
+        n_ref = min(args.e2e_utrs, n_ref_files * 128)
         t0 = time.perf_counter()
-        infer_files(files, root, device=dev, rng_mode="reference", seed=1, re_run_mode=False,
+        infer_files(ref_files, root, device=dev, rng_mode="reference", seed=1, re_run_mode=True,
                     n_max_apa=args.kcap, n_min_apa=1)
         dt3 = time.perf_counter() - t0
-        reference_streams = dict(value=args.e2e_utrs / dt3, seconds=dt3, chunk_files_in_flight=min(128, len(files)))
+        reference_streams = dict(value=n_ref / dt3, utrs=n_ref, seconds=dt3, re_run_mode=True,
+                                 chunk_files_in_flight=min(128, len(ref_files)))
         return dict(value=args.e2e_utrs / dt, unit="UTRs/s", utrs=args.e2e_utrs, seconds=dt, prep_workers=pool.workers,
                     from_prebinned_chunks=prebinned, reference_streams=reference_streams,
                     chunk_files=len(files), input_bytes=in_bytes, output_bytes=out_bytes,
@@ -200,15 +241,111 @@ def end_to_end(args, pool, dev):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def single_chunk_reference(args, dev):
+    """`scape infer_pa` as the reference is used - ONE chunk file, its own random stream (np.random.seed(1),
+    apa_core.py:125), re_run_mode on: the small-call latency path."""
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    n = 128
+    kw = dict(n_max_apa=args.kcap, n_min_apa=1)
+    preps = []
+    for i in range(n):
+        g, df, _ = synth_utr(2 * 10 ** 6 + i, args.reads, k_cap=args.kcap, base_seed=args.base_seed)
+        preps.append(prepare_utr(df, gene_info_str=g, **kw))
+    eng = Engine(device=dev)
+    eng.run(preps[:8], rng_mode="reference", seed=1, re_run_mode=True)          # warm-up (allocations)
+    t0 = time.perf_counter()
+    eng.run(preps, rng_mode="reference", seed=1, re_run_mode=True)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="UTRs/s", utrs=n, seconds=dt, rng_mode="reference", re_run_mode=True,
+                note="one chunk file of 128 UTRs, UTRs strictly one after another (prepared UTRs resident on the host)")
+
+
+def end_to_end_multi(args, pool, gpus):
+    """The product path on N GPUs: `infer_pa_all --gpus N` (scape_amd.apa_core.infer_all) over chunk files of
+    BASELINE config #4's shape (10k reads per UTR), one worker process + prep pool per GPU, chunk files sharded
+    by size, no collective.  Reports the per-worker pipeline stage seconds so the host-side limit is visible.
+    Runs in a process that has not initialised the GPU (or whose fork server was started before it did)."""
+    import shutil
+    import tempfile
+    from scape_amd.apa_core import infer_all
+    n_utrs = args.e2e_multi_utrs * gpus
+    root = tempfile.mkdtemp(prefix="scape_e2e_multi_")
+    try:
+        files, t_write = write_synth_chunks(pool, root, n_utrs, args.e2e_multi_reads, args.kcap, args.base_seed,
+                                            per_file=64, first_index=3 * 10 ** 6)
+        in_bytes = sum(os.path.getsize(f) for f in files)
+        st = {}
+        t0 = time.perf_counter()
+        infer_all(root, gpus=gpus, stats=st, rng_mode="per_utr", seed=args.base_seed, re_run_mode=False,
+                  n_max_apa=args.kcap, n_min_apa=1)
+        dt = time.perf_counter() - t0
+        outs = [os.path.join(root, "pkl_output", os.path.basename(f)[:-10] + ".res.pkl") for f in files]
+        assert all(os.path.exists(o) for o in outs), "a chunk has no result file"
+        return dict(value=n_utrs / dt, unit="UTRs/s", n_gpus=gpus, utrs=n_utrs, seconds=dt,
+                    workload=f"{n_utrs} synthetic UTRs x {args.e2e_multi_reads} reads, K=1..{args.kcap} "
+                             f"(BASELINE config #4 shape), {len(files)} chunk files -> .res.pkl, rng_mode per_utr",
+                    chunk_files=len(files), input_bytes=in_bytes, synth_write_s=t_write,
+                    workers=st.get("workers"), prep_workers_per_gpu=st.get("prep_workers_per_gpu"), host=host_info())
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process
+    never touches the GPU), then run the multi-GPU end-to-end leg here and print ONE JSON line."""
+    import socket
+    import subprocess
+    pool = None
+    if args.e2e_multi_utrs > 0:
+        from scape_amd.pipeline import shared_pool
+        pool = shared_pool(args.e2e_workers or None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SCAPE_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n{out0}\n")
+        sys.exit(1)
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n" + out0 + "\n")
+        sys.exit(1)
+    out = json.loads(line)
+    if pool is not None:
+        out["end_to_end_multi_gpu"] = end_to_end_multi(args, pool, args.gpus)
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a wrong n_gpus\n")
+        sys.exit(2)
+    child = os.environ.get("SCAPE_BENCH_CHILD") == "1"       # ranks started by launch_ranks: the parent runs the e2e legs
     dist = None
     pool = None
-    if world == 1 and args.e2e_utrs > 0:
-        # the end-to-end leg's prep workers: started before this process touches the GPU, idle until then
+    want_e2e = (world == 1 and args.e2e_utrs > 0) or (world > 1 and rank == 0 and not child and args.e2e_multi_utrs > 0)
+    if want_e2e:
+        # the end-to-end legs' prep workers (and the fork server the multi-GPU workers come from): started before
+        # this process touches the GPU, idle until then
         from scape_amd.pipeline import shared_pool
         pool = shared_pool(args.e2e_workers or None)
     from scape_amd import _lib as _sl
@@ -219,7 +356,8 @@ def main():
         # initialised - torch bundles its own HIP runtime and this library links the system one.
         import torch
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo")
+        import datetime
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(hours=1))   # ranks wait while rank 0 runs the e2e leg
         tdev = torch.device("cpu")
 
     from scape_amd.engine import Engine, HipBatch
@@ -245,26 +383,33 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def timed(fn, steps):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, r
+
+    em_ms = [0.0]
+
     def step():
-        return eng.process(batch, preps, plan, re_run_mode=False)
+        r = eng.process(batch, preps, plan, re_run_mode=False)
+        em_ms[0] += eng.last_main_em_ms
+        return r
 
     for _ in range(args.warmup):
         res = step()
     lib, h = eng.ctx.lib, eng.ctx.h
     lib.scape_hip_timing_reset(h)
-    sync_all()
-    em_ms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        em_ms += eng.last_main_em_ms
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    em_ms[0] = 0.0
+    elapsed, res = timed(step, args.steps)
 
     # kernel timing (HIP events on the library's stream) of the timed steps
     kern = {}
@@ -273,14 +418,23 @@ def main():
         lib.scape_hip_timing_get(h, which, ctypes.byref(ms), ctypes.byref(n))
         kern[name] = dict(ms_total=ms.value, launches=n.value)
     rounds, slab, zel = eng.last_main_counters
-    em_avg_ms = em_ms / args.steps
+    em_avg_ms = em_ms[0] / args.steps
+    host_ms = dict(eng.last_host_ms)
+
+    # the same timed region with re_run_mode on (the reference's default): UTRs whose K hits the cap
+    # get a second, larger sweep through the generic state machine
+    rr_steps = max(1, min(args.steps, 2))
+    rr_elapsed, _ = timed(lambda: eng.process(batch, preps, plan, re_run_mode=True), rr_steps)
+
     # one extra, untimed step with an event pair around every per-round kernel: average duration of the
-    # dominant kernel (k2_mstep, one launch per EM round) measured live on the launch stream
+    # dominant kernel (k2_mstep, one launch per EM round) measured live on the launch stream, and the
+    # kernel's own byte tally of that sweep
     os.environ["SCAPE_HIP_ROUND_TIMING"] = "1"
     lib.scape_hip_timing_reset(h)
     batch.build()
     batch.em_packed(plan["main"])
     del os.environ["SCAPE_HIP_ROUND_TIMING"]
+    traffic = batch.em_traffic()
     per = {}
     for which, name in ((4, "k2_estep"), (5, "k2_mstep")):
         ms, n = ctypes.c_double(), ctypes.c_int32()
@@ -289,12 +443,12 @@ def main():
         kern[name + "_profiled_step"] = dict(ms_total=ms.value, launches=n.value)
     m_ms, m_n = per["k2_mstep"]
     m_avg_ms = m_ms / max(m_n, 1)
-    alg_bytes = 8.0 * slab / max(m_n, 1)                # SURVEY.md 8(d) slab term, per M-step launch
-    achieved = alg_bytes / (m_avg_ms * 1e-3) / 1e9
+    assert traffic["launches"] == m_n, (traffic, m_n)
+    alg_bytes = 8.0 * slab / max(m_n, 1)                # SURVEY.md 8(d) slab term (job-at-a-time), per M-step launch
+    hbm_bytes = (traffic["tensor_bytes"] + traffic["v_bytes_unique"]) / max(m_n, 1)
+    achieved = hbm_bytes / (m_avg_ms * 1e-3) / 1e9
     tensor_bytes = 8.0 * sum(q.T * len(q.betas) * ((q.N + 15) // 16 * 16) for q in preps)
 
-    # the PMC figure was measured on the default workload only
-    pmc_traffic = PMC_TRAFFIC_BYTES_PER_LAUNCH if (U, args.reads, args.kcap) == (512, 2000, 10) else None
     if rank == 0:
         N = np.array([q.N for q in preps])
         T = np.array([q.T for q in preps])
@@ -312,19 +466,28 @@ def main():
                        "rng_mode": "per_utr", "parallelism": f"utr-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k2_mstep (tile-stationary f64-MFMA M-step, one launch per EM round)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "hbm_actual_gbs": pmc_traffic / (m_avg_ms * 1e-3) / 1e9 if pmc_traffic else None,
-                         "hbm_actual_frac": pmc_traffic / (m_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pmc_traffic else None,
+                         "traffic": hbm_bytes,
+                         "traffic_source": "tallied by the kernel itself (scape_hip_em_traffic): tensor-tile bytes "
+                                           "streamed + each job's v vector once, per launch; the rocprofv3 FETCH_SIZE "
+                                           "pass of the same command is in profiles/ (README: how they compare)",
+                         "traffic_tensor_bytes": traffic["tensor_bytes"] / max(m_n, 1),
+                         "traffic_v_bytes_unique": traffic["v_bytes_unique"] / max(m_n, 1),
+                         "v_bytes_requested_incl_l2_hits": traffic["v_bytes_requested"] / max(m_n, 1),
                          "launch_ms": m_avg_ms, "launches_per_sweep": m_n,
+                         "algorithmic_bytes_per_launch": alg_bytes, "reuse_factor": alg_bytes / max(hbm_bytes, 1.0),
                          "tensor_bytes_streamed_once": tensor_bytes,
-                         "note": "algorithmic bytes = 8*N*B*|window| summed over the jobs and rounds (what a "
-                                 "job-at-a-time M-step reads); the kernel streams each tensor tile once per round "
-                                 "for all jobs that need it, so achieved exceeds the HBM peak by the reuse factor; "
-                                 "hbm_actual_* = PMC-measured bytes per launch (traffic, default workload) / launch_ms",
+                         "note": "achieved = traffic / launch_ms (HIP events on the launch stream).  "
+                                 "algorithmic_bytes_per_launch = SURVEY.md 8(d)'s 8*N*B*|window| summed over jobs "
+                                 "(what a job-at-a-time M-step reads); the kernel streams each live tensor tile once "
+                                 "per round for all jobs that need it: reuse_factor = algorithmic / traffic",
                          "em_sweep_ms": em_avg_ms, "em_rounds_per_sweep": int(rounds),
                          "mfma_f64_tflops": 2.0 * slab / (m_ms * 1e-3) / 1e12},
             "kernels_ms": kern,
-            "host": {"prep_s": t_prep, "h2d_s": t_h2d, "process_ms": eng.last_host_ms},
+            "re_run_mode_true": {"value": world * U * rr_steps / rr_elapsed, "unit": "UTRs/s", "steps": rr_steps,
+                                 "ms_per_step": 1e3 * rr_elapsed / rr_steps,
+                                 "note": "same resident batch and timed region with the re-run rule of subsample_run "
+                                         "(apa_core.py:1023-1030) on"},
+            "host": {"prep_s": t_prep, "h2d_s": t_h2d, "process_ms": host_ms, **host_info()},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
@@ -333,12 +496,20 @@ def main():
             same = parity_count(preps, plan, res, outs)
             out["cpu_baseline"]["parity_sample"] = f"{same}/{len(outs)} sampled UTRs: GPU pA calls identical to the CPU port"
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / cb["value"]
-        if pool is not None:
-            batch.free()
+            out["cpu_baseline"].update(host_info())
+    batch.free()
+    if rank == 0:
+        if world == 1 and pool is not None:
+            out["single_chunk_reference"] = single_chunk_reference(args, dev)
             out["end_to_end"] = end_to_end(args, pool, dev)
+    if dist is not None:
+        dist.barrier()                           # every rank has released its batch
+        if rank == 0 and pool is not None:
+            out["end_to_end_multi_gpu"] = end_to_end_multi(args, pool, world)
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
 
 

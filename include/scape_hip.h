@@ -30,11 +30,12 @@
 extern "C" {
 #endif
 
-#define SCAPE_HIP_ABI_VERSION 1
+#define SCAPE_HIP_ABI_VERSION 2
 #define SCAPE_SENT (-3.4028234663852886e38)
 #define SCAPE_MAX_BETA 64    /* max len(predef_beta_arr) */
 #define SCAPE_MAX_S 64       /* max len(s_dis_arr)       */
 #define SCAPE_MAX_K 31       /* max number of pA components per model (K+1 <= 32) */
+#define SCAPE_MAX_JOBS_PER_UTR 1024  /* max non-fixed jobs on one UTR in one scape_hip_batch_em call */
 
 typedef struct scape_hip_ctx scape_hip_ctx;
 
@@ -107,6 +108,9 @@ int scape_hip_batch_build(scape_hip_ctx *ctx);
  * ws) and the update order k_arr (gen_k_arr, apa_core.py:653-677); job_fixed[j] != 0 selects
  * mstep_fixed (apa_core.py:552-557).  Tables are padded to kmax / kmax+1 / nround per job.
  * Outputs (same padding): sorted alpha_idx / beta_idx / ws, bic, lb_arr and its length.
+ * Limits (checked, an error is returned): kmax <= SCAPE_MAX_K; at most SCAPE_MAX_JOBS_PER_UTR jobs with
+ * job_fixed == 0 on any one UTR per call (the reference's own sweep is (n_max_apa - n_min_apa + 1) * 10
+ * jobs per UTR, apa_core.py:846-871, :965).
  */
 int scape_hip_batch_em(scape_hip_ctx *ctx, int32_t n_jobs, int32_t kmax, const int32_t *job_utr,
                        const int32_t *job_K, const int32_t *job_fixed, const int32_t *alpha_idx,
@@ -140,6 +144,13 @@ int scape_hip_timing_get(scape_hip_ctx *ctx, int32_t which, double *ms_total, in
    by the grid arg-max M-step, apa_core.py:507-523), and of rounds x n_frag x (K+1) */
 int scape_hip_em_counters(scape_hip_ctx *ctx, int64_t *rounds, int64_t *slab_elems,
                           int64_t *z_elems);
+
+/* HBM-side byte tally of the M-step kernel over the last scape_hip_batch_em call, counted by the kernel
+   itself: tensor-tile bytes it streamed (each live 64-row tile x the bins it needs, once per round), the
+   v-vector bytes as requested by every workgroup (mostly L2 hits) and counted once per (job, round), and
+   the number of M-step launches.  Replaces nothing in the reference (measurement only). */
+int scape_hip_em_traffic(scape_hip_ctx *ctx, int64_t *mstep_tensor_bytes, int64_t *mstep_v_bytes_requested,
+                         int64_t *mstep_v_bytes_unique, int64_t *mstep_launches);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "scape_hip_timing_reset": (c_i, [P_void]),
     "scape_hip_timing_get": (c_i, [P_void, c_i32, P_d, P_i32]),
     "scape_hip_em_counters": (c_i, [P_void, P_i64, P_i64, P_i64]),
+    "scape_hip_em_traffic": (c_i, [P_void, P_i64, P_i64, P_i64, P_i64]),
 }
 
 _lib = None
@@ -76,7 +77,7 @@ def load_library():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.scape_hip_abi_version() != 1:
+        if lib.scape_hip_abi_version() != 2:
             raise ScapeHipError("libscape_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -206,24 +206,33 @@ def infer_files(files, output_dir, device=None, files_in_flight=128, workers=Non
     return written
 
 
-def _infer_files_worker(rank, files, output_dir, kwargs, workers):
+def _infer_files_worker(rank, files, output_dir, kwargs, workers, stats_file=None):
     os.environ["LOCAL_RANK"] = str(rank)
     from . import _lib
     from .pipeline import close_shared_pool, shared_pool
     shared_pool(workers)                                   # prep workers first: they never see a HIP context
     try:
         device = rank % max(1, _lib.device_count())        # more workers than GPUs only happens in tests
-        infer_files(files, output_dir, device=device, workers=workers, **kwargs)
+        st = {}
+        t0 = timer()
+        infer_files(files, output_dir, device=device, workers=workers, stats=st, **kwargs)
+        if stats_file:
+            import json
+            st.update(rank=rank, device=device, chunk_files=len(files), wall_s=timer() - t0)
+            with open(stats_file, "w") as fh:
+                json.dump({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}, fh)
     finally:
         close_shared_pool()                                # or this process never gets past its exit join
 
 
-def infer_all(output_dir, gpus=1, resume=False, **kwargs):
+def infer_all(output_dir, gpus=1, resume=False, stats=None, **kwargs):
     """Every complete chunk of <output_dir>/pkl_input on `gpus` GPUs of this node: chunk files are sharded
     over one worker process per GPU (largest-first by file size), no communication between workers
     (merge_pa expects one .res.pkl per .input.pkl, reference junction_handler.py:59-64).
     resume: leave out the chunks whose .res.pkl already exists and is not older than the chunk (result files
-    are written under a temporary name and renamed, so an existing one is complete)."""
+    are written under a temporary name and renamed, so an existing one is complete).
+    stats: optional dict; receives `workers` = the pipeline stage seconds of every worker process and
+    `prep_workers_per_gpu`."""
     import glob
     import multiprocessing as mp
 
@@ -243,7 +252,10 @@ def infer_all(output_dir, gpus=1, resume=False, **kwargs):
             return []
     shards = lpt_partition([os.path.getsize(f) for f in files], gpus)
     if gpus == 1:
-        infer_files(files, output_dir, device=kwargs.pop("device", None), **kwargs)
+        st = {}
+        infer_files(files, output_dir, device=kwargs.pop("device", None), stats=st, **kwargs)
+        if stats is not None:
+            stats.update(workers=[dict(st, rank=0, chunk_files=len(files))], prep_workers_per_gpu=None)
         return files
     # fork-server children: no exec from this process (which may already hold a HIP context, e.g. under pytest),
     # and the workers are born without one
@@ -253,16 +265,33 @@ def infer_all(output_dir, gpus=1, resume=False, **kwargs):
     except AttributeError:
         n_cpu = os.cpu_count() or 1
     workers = max(1, min(14, n_cpu // gpus - 2))               # prep processes per GPU worker
-    procs = [ctx.Process(target=_infer_files_worker,
-                         args=(r, [files[i] for i in shards[r]], output_dir, kwargs, workers))
-             for r in range(gpus) if shards[r]]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join()
-    bad = [p.exitcode for p in procs if p.exitcode != 0]
-    if bad:
-        raise Exception(f"infer_pa_all: {len(bad)} worker(s) failed")
+    import json
+    import shutil
+    import tempfile
+    sdir = tempfile.mkdtemp(prefix="scape_stats_") if stats is not None else None
+    try:
+        procs = [ctx.Process(target=_infer_files_worker,
+                             args=(r, [files[i] for i in shards[r]], output_dir, kwargs, workers,
+                                   os.path.join(sdir, f"rank{r}.json") if sdir else None))
+                 for r in range(gpus) if shards[r]]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join()
+        bad = [p.exitcode for p in procs if p.exitcode != 0]
+        if bad:
+            raise Exception(f"infer_pa_all: {len(bad)} worker(s) failed")
+        if stats is not None:
+            per = []
+            for r in range(gpus):
+                f = os.path.join(sdir, f"rank{r}.json")
+                if os.path.exists(f):
+                    with open(f) as fh:
+                        per.append(json.load(fh))
+            stats.update(workers=per, prep_workers_per_gpu=workers)
+    finally:
+        if sdir:
+            shutil.rmtree(sdir, ignore_errors=True)
     return files
 
 

@@ -7,9 +7,11 @@
 //   labels   get_label                    apa_core.py:873-881
 // How it is computed is MI355X-first: every array keeps the bin axis (n) fastest so that the
 // 64 lanes of a wavefront read/write consecutive f64; rows are padded to a 16-element pitch so
-// rows start 128-B aligned and can be read as double2; the EM kernel runs one workgroup per
-// (UTR, K, restart) job, keeps the responsibility column of the component being updated in LDS
-// and streams the tensor slab of the grid arg-max M-step with wavefront-shuffle reductions.
+// rows start 128-B aligned and can be read as double2.  The EM advances all (UTR, K, restart) jobs of a call
+// in lock-step rounds (em_lockstep.inc): k2_estep, one wavefront per job (responsibilities, weights, ELBO),
+// then k2_mstep, one workgroup per (UTR, 64-row tensor tile), which multiplies the tile with the v vectors of
+// every job whose window covers it on the f64 matrix cores and keeps per-(job, tile) first arg-maxes.
+// k_em below is the round-1 job-at-a-time kernel (SCAPE_HIP_EM=v1, A/B runs only).
 // All arithmetic is f64 (the reference's finite -inf sentinel overflows f32).
 #include <hip/hip_runtime.h>
 
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                                                  const double *__restrict__ AT,
                                                  const double *__restrict__ V,
                                                  double *__restrict__ M, int Wmax, int all_log,
-                                                 int *__restrict__ err_flag, int n_utr, int T_max) {
+                                                 int *__restrict__ err_flag, int n_utr, int T_max, int probe) {
     extern __shared__ double sm[];
     // blocks b and b+8 share an XCD: all grid points of a UTR go to one XCD so its V rows (each is
     // read by ~43 neighbouring alphas) are fetched into one L2 only.  Placement only affects speed.
@@ -291,6 +293,8 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
     if (tid < B) {  // call_logp_theta_sum_kernel (taichi_core.py:160-169), serial order
         double psum = 0.0;
         const int W = hi[tid] - lo[tid] + 1;
+        if (probe & 4) psum = 1.0;
+        else
         for (int w = 0; w < W; ++w) psum += exp(g[(size_t)tid * Wmax + w]);
         G[tid] = log(psum);
     }
@@ -321,7 +325,8 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
     // v_mfma_f64_16x16x4_f64 covers 16 betas (13 used) x 16 bins x 4 taps.  A = weights from LDS (lane l:
     // beta l&15, tap l>>4), B = V straight from global/L2 (lane l: tap l>>4, bin l&15), D lane l reg q:
     // beta (l>>4)+4q, bin l&15.
-    if (!all_log && BMAX == 16) {
+    if (probe & 2) {
+    } else if (!all_log && BMAX == 16) {
         typedef double v4d __attribute__((ext_vector_type(4)));
         const int WP = ((Wmax + 3) & ~3) + 1;                     // odd pitch: conflict-light fragment reads
         double *pm = reinterpret_cast<double *>(hi + B + (B & 1)); // [16][WP], zero outside window / beyond B
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
             for (int j = 0; j < B; ++j) Mi[(size_t)j * d.Np + n] = 0.0;
     }
     // ---- log-domain path (cal_res_kernel, taichi_core.py:172-179) ------------------------------
-    const int n_log = all_log ? d.N : d.n_log;
+    const int n_log = (probe & 1) ? 0 : (all_log ? d.N : d.n_log);
     const double *Au = AT + (size_t)d.at_off;
     for (int item = tid; item < n_log * B; item += blockDim.x) {
         const int j = item / n_log, q = item - j * n_log;
@@ -819,7 +824,7 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
-#define N_COUNTERS (4 + 2 * 64)   // rounds, slab elements (v1), z elements, unused, then 64 + 64 shards (em_lockstep.inc)
+#define N_COUNTERS (4 + 5 * 64)   // rounds, slab elements (v1), z elements, unused, then five 64-way sharded counters (em_lockstep.inc)
 struct scape_hip_ctx {
     int device = 0;
     std::atomic<bool> busy{false};   // a handle serves one host thread at a time (scape_hip.h)
@@ -843,6 +848,7 @@ struct scape_hip_ctx {
     double ms_acc[6] = {0, 0, 0, 0, 0, 0};
     int n_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long h_counters[3] = {0, 0, 0};
+    unsigned long long h_traffic[4] = {0, 0, 0, 0};   // last EM call: M-step tensor bytes, v bytes requested / unique, launches
 };
 
 static int ev_begin(scape_hip_ctx *c, int which) {
@@ -939,12 +945,14 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
                        (size_t)16 * (((Wmax + 3) & ~3) + 1) * sizeof(double);
     if (lds > 150 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
     dim3 grid((unsigned)(((n_utr + 7) / 8) * 8 * T_max));
+    const char *pe = getenv("SCAPE_HIP_PB_PROBE");   // timing probe (results are wrong with it): 1 no log path, 2 no linear path, 4 no G exps
+    const int probe = pe ? atoi(pe) : 0;
     if (prm.B <= 16)
         hipLaunchKernelGGL(k_phase_b<16>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, probe);
     else
         hipLaunchKernelGGL(k_phase_b<1>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, probe);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1117,7 +1125,8 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                                    c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, tiles_max,
                                    c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo,
                                    S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row,
-                                   c->d_tile_nend.as<int32_t>(), dbg);
+                                   c->d_tile_nend.as<int32_t>(), c->d_counters.as<unsigned long long>(), dbg);
+                c->h_traffic[3] += 1;
                 HIPCHK(hipGetLastError());
                 if (fine && ev_end(c, 5)) return 1;
             }
@@ -1126,7 +1135,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             // early exit: no job executed a round since the last probe -> every job has been finalised
             unsigned long long executed = 0, shard[64];
             if (split) HIPCHK(hipStreamSynchronize(c->stream2));
-            HIPCHK(hipMemcpyAsync(shard, c->d_counters.as<unsigned long long>() + 4 + 64, sizeof(shard),
+            HIPCHK(hipMemcpyAsync(shard, c->d_counters.as<unsigned long long>() + CNT_EXEC, sizeof(shard),
                                   hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             for (int i = 0; i < 64; ++i) executed += shard[i];
@@ -1497,6 +1506,14 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
             if (k < 0 || k > K || (K > 0 && k >= K)) return fail("job " + std::to_string(j) + ": k_arr entry out of range");
         }
     }
+    {
+        // k2_mstep keeps the per-tile list of a UTR's jobs in a fixed LDS table (em_lockstep.inc, s_all)
+        std::vector<int32_t> per_utr(c->n_utr, 0);
+        for (int j = 0; j < n_jobs; ++j)
+            if (!job_fixed[j] && ++per_utr[job_utr[j]] > SCAPE_MAX_JOBS_PER_UTR)
+                return fail("UTR " + std::to_string(job_utr[j]) + ": more than " + std::to_string(SCAPE_MAX_JOBS_PER_UTR) +
+                            " non-fixed jobs in one call (split the call)");
+    }
     const size_t nj = n_jobs;
     if (c->j_utr.ensure(nj * 4) || c->j_K.ensure(nj * 4) || c->j_fixed.ensure(nj * 4) || c->j_a.ensure(nj * kmax * 4) ||
         c->j_b.ensure(nj * kmax * 4) || c->j_ws.ensure(nj * (kmax + 1) * 8) || c->j_karr.ensure(nj * nround) ||
@@ -1512,6 +1529,7 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipMemcpyAsync(c->j_karr.p, k_arr, nj * nround, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_counters.p, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->j_lb.p, 0, nj * nround * 8, c->stream));
+    c->h_traffic[3] = 0;
     const char *mode = getenv("SCAPE_HIP_EM");
     const bool use_v1 = mode && strcmp(mode, "v1") == 0;
     if (ev_begin(c, 2)) return 1;
@@ -1545,7 +1563,13 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipMemcpyAsync(hc, c->d_counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; ++i) c->h_counters[i] = hc[i];
-    for (int i = 0; i < 64; ++i) c->h_counters[1] += hc[4 + i];   // sharded slab-element counter of the lock-step EM
+    c->h_traffic[0] = c->h_traffic[1] = c->h_traffic[2] = 0;
+    for (int i = 0; i < 64; ++i) {
+        c->h_counters[1] += hc[CNT_SLAB + i];   // sharded slab-element counter of the lock-step EM
+        c->h_traffic[0] += hc[CNT_MSTEP_TENSOR + i];
+        c->h_traffic[1] += hc[CNT_MSTEP_VREQ + i];
+        c->h_traffic[2] += hc[CNT_MSTEP_VUNI + i];
+    }
     return 0;
 }
 
@@ -1661,6 +1685,16 @@ int scape_hip_em_counters(scape_hip_ctx *c, int64_t *rounds, int64_t *slab_elems
     if (rounds) *rounds = (int64_t)c->h_counters[0];
     if (slab_elems) *slab_elems = (int64_t)c->h_counters[1];
     if (z_elems) *z_elems = (int64_t)c->h_counters[2];
+    return 0;
+}
+
+int scape_hip_em_traffic(scape_hip_ctx *c, int64_t *mstep_tensor_bytes, int64_t *mstep_v_bytes_requested,
+                         int64_t *mstep_v_bytes_unique, int64_t *mstep_launches) {
+    if (!c) return fail("ctx is NULL");
+    if (mstep_tensor_bytes) *mstep_tensor_bytes = (int64_t)c->h_traffic[0];
+    if (mstep_v_bytes_requested) *mstep_v_bytes_requested = (int64_t)c->h_traffic[1];
+    if (mstep_v_bytes_unique) *mstep_v_bytes_unique = (int64_t)c->h_traffic[2];
+    if (mstep_launches) *mstep_launches = (int64_t)c->h_traffic[3];
     return 0;
 }
 

@@ -195,6 +195,14 @@ class HipBatch:
               "em_counters")
         return r.value, s.value, z.value
 
+    def em_traffic(self):
+        """The M-step kernel's own byte tally over the last em call: dict(tensor_bytes, v_bytes_requested,
+        v_bytes_unique, launches) (scape_hip_em_traffic)."""
+        t, vr, vu, n = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(self.lib.scape_hip_em_traffic(self.ctx.h, ctypes.byref(t), ctypes.byref(vr), ctypes.byref(vu),
+                                            ctypes.byref(n)), "em_traffic")
+        return dict(tensor_bytes=t.value, v_bytes_requested=vr.value, v_bytes_unique=vu.value, launches=n.value)
+
     def labels(self, sel):
         """sel: list of (u, Fit) -> dict u -> int32 labels per bin (get_label, :873-881)."""
         if not sel:
@@ -238,6 +246,14 @@ class HipBatch:
         check(self.lib.scape_hip_batch_free(self.ctx.h), "batch_free")
 
 
+def _no_component_left(q):
+    """rm_component with every pA component below min_ws: the reference indexes alpha_arr with an empty float
+    array (apa_core.py:838-839) and dies with this IndexError; there is no result to reproduce."""
+    raise IndexError(f"{q.gene_info_str}: every pA component has weight < min_ws={q.p['min_ws']} "
+                     "(the reference's rm_component fails here too: arrays used as indices must be of integer "
+                     "(or boolean) type, apa_core.py:838-839)")
+
+
 class _Sweep:
     """Per-UTR state machine of run() / subsample_run()'s re-run loop."""
 
@@ -262,6 +278,8 @@ class _Sweep:
             f = self.best
             keep = np.array([i for i in range(f.K) if not f.ws[i] < q.p["min_ws"]], dtype=int)
             Kp = len(keep)
+            if Kp == 0:
+                _no_component_left(q)
             w = self.sampler.init_ws(Kp, q.p["max_unif_ws"])
             ka = self.sampler.k_arr(Kp)
             jobs.append(_Job(self.u, Kp, True, f.a_idx[keep].astype(np.int32), f.b_idx[keep].astype(np.int32), w, ka))
@@ -336,6 +354,15 @@ class _Sweep:
     def _after_fit(self):
         # re-run rule of subsample_run (:1023-1030); fixed_run returns before it (:1009-1017)
         if self.re_run and not self.prep.fixed_run and self.best.K == self.n_max:
+            if self.n_max + 2 > _lib.MAX_K:
+                # the reference grows n_max_apa without bound (:1023-1030); the kernels hold K <= MAX_K components.
+                # Only this UTR stops re-running - the other UTRs of the wave and file are unaffected.
+                import sys
+                sys.stderr.write(f"scape_amd: {self.prep.gene_info_str}: K reached n_max_apa={self.n_max} and the "
+                                 f"next sweep would exceed the library's K <= {_lib.MAX_K}; keeping K={self.best.K} "
+                                 "(the reference would re-run with n_max_apa + 2)\n")
+                self.done = True
+                return
             self.n_min = self.n_max
             self.n_max = self.n_max + 2
             self.stage = "sweep"
@@ -649,6 +676,8 @@ class Engine:
         if len(pu):
             keep = comp[pu] & ~(wo[win[pu], :pj.kmax] < min_ws[pu, None])
             Kp = keep.sum(axis=1)
+            if np.any(Kp == 0):
+                _no_component_left(preps[int(pu[int(np.argmin(Kp))])])
             order = np.argsort(~keep, axis=1, kind="stable")              # kept components first, in order
             kmp = max(1, int(Kp.max()))
             sel = np.arange(kmp)[None, :] < Kp[:, None]

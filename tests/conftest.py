@@ -62,5 +62,5 @@ def hip_ctx():
     return _lib.default_context(0)
 
 
-TRACES = ["synA", "synB", "synF", "chr17", "chr19", "toy"]
+TRACES = ["synA", "synB", "synC", "synD", "synE", "synF", "chr17", "chr19", "toy"]
 FIXTURES = ["chr17", "chr19", "toy"]

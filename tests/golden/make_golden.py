@@ -28,7 +28,7 @@ reference never travels: only the ``.npz`` files do.
    of the reference's own ``proc_junction_{pos,neg}_pa`` run here on randomly generated genes
    (several UTR records per gene, junction reads that trigger merges, tied positions, empty sites).
 
-Usage: python tests/golden/make_golden.py [fixtures|traces|synth|fixed|merge|all] [names...]
+Usage: python tests/golden/make_golden.py [fixtures|traces|synth|fixed|highk|merge|all] [names...]
 """
 from __future__ import annotations
 
@@ -349,6 +349,33 @@ def write_synth():
     run_reference_file("synB", utrs, p, seed=7, keep_full_tensor=True)
 
 
+def write_highk():
+    """K = 6..13 (7..14 columns of log Z): the branches of the row sums that start at 8 columns (np.sum's
+    unrolled-by-8 order) and the E-step code variants above K = 5 - none of which the K <= 5 traces reach.
+    synC: K sweep 8..6 (apa_core.py:965); synD: n_max = n_min = 11 with min_ws = 0 (nothing is pruned), so K = 11
+    hits the cap and subsample_run re-runs with K = 13..11 (:1023-1030); synE: K = 10, 9."""
+    rng = np.random.default_rng(20251004)
+    utrs = [
+        ("synC:g1:1:1-2600:+", synth_utr(rng, 230, [450, 900, 1300, 1750, 2200], [15, 25, 20, 35, 30],
+                                          [0.2, 0.2, 0.2, 0.2, 0.2], 2600, pa_rate=0.04)),
+        ("synC:g2:1:1-2000:-", synth_utr(rng, 180, [500, 1000, 1500], [20, 40, 25], [0.3, 0.4, 0.3], 2000,
+                                          pa_rate=0.02, r_rate=0.05)),
+    ]
+    p = dict(DEFAULT_PARAMS)
+    p.update(n_max_apa=8, n_min_apa=6)
+    run_reference_file("synC", utrs, p, seed=1, tensor_stride=7)
+    utrs = [("synD:g1:1:1-2400:+", synth_utr(rng, 210, [400, 800, 1200, 1600, 2000], [20, 20, 30, 25, 35],
+                                              [0.25, 0.15, 0.2, 0.2, 0.2], 2400, pa_rate=0.05))]
+    p = dict(DEFAULT_PARAMS)
+    p.update(n_max_apa=11, n_min_apa=11, min_ws=0.0)
+    run_reference_file("synD", utrs, p, seed=5, tensor_stride=7)
+    utrs = [("synE:g1:1:1-2000:+", synth_utr(rng, 170, [600, 1100, 1600], [25, 30, 20], [0.4, 0.3, 0.3], 2000,
+                                              pa_rate=0.03))]
+    p = dict(DEFAULT_PARAMS)
+    p.update(n_max_apa=10, n_min_apa=9, re_run_mode=False)
+    run_reference_file("synE", utrs, p, seed=9, tensor_stride=7)
+
+
 def write_fixed():
     """fixed_run_mode (apa_core.py:883-928, :999-1017): two synthetic UTRs, K and grids from a given result."""
     rng = np.random.default_rng(77)
@@ -544,6 +571,8 @@ if __name__ == "__main__":
         write_synth()
     if what in ("fixed", "all"):
         write_fixed()
+    if what in ("highk", "all"):
+        write_highk()
     if what in ("merge", "all"):
         write_merge_fixtures()
         write_merge_trace()

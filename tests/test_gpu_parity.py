@@ -195,6 +195,12 @@ def test_full_pipeline_reference_stream(name):
 
 
 # ---------------------------------------------------------------- CLI end to end vs the committed example outputs
+# (fixture, UTR) -> (ws abs tolerance, bic rel tolerance) where the reference at its current code reproduces the
+# committed K / alpha / beta / labels exactly (measured: tests/golden/trace_*.npz res_* vs fixture_*.npz gold_*);
+# ws / bic of the committed files come from an older init path and a loose stopping rule
+GOLDEN_EXACT = {("chr17", 0): (5e-5, 1e-5), ("toy", 0): (2e-3, 1.2e-2)}
+
+
 @pytest.mark.parametrize("name", FIXTURES)
 def test_cli_on_example_chunks_vs_committed_goldens(tmp_path, name):
     from click.testing import CliRunner
@@ -231,10 +237,23 @@ def test_cli_on_example_chunks_vs_committed_goldens(tmp_path, name):
         tag = (name, i)
         assert para.gene_info_str == str(f[f"u{i}_gene_info_str"])
         assert para.K == int(f[f"u{i}_gold_K"]) and para.L == int(f[f"u{i}_gold_L"]), tag
-        assert np.all(np.abs(para.alpha_arr - f[f"u{i}_gold_alpha_arr"]) <= 9), tag
-        assert np.mean(para.label_arr == f[f"u{i}_gold_label_arr"]) >= 0.99, tag
-        assert np.allclose(para.ws, f[f"u{i}_gold_ws"], atol=2e-2), tag
-        assert para.bic == pytest.approx(float(f[f"u{i}_gold_bic"]), rel=2e-2), tag
+        if tag in GOLDEN_EXACT:
+            # the current reference code reproduces its committed output here: K, alpha, beta and EVERY label
+            ws_atol, bic_rel = GOLDEN_EXACT[tag]
+            assert np.array_equal(para.alpha_arr, f[f"u{i}_gold_alpha_arr"]), tag
+            assert np.array_equal(para.beta_arr, f[f"u{i}_gold_beta_arr"]), tag
+            assert np.array_equal(para.label_arr, f[f"u{i}_gold_label_arr"]), tag
+            assert np.allclose(para.ws, f[f"u{i}_gold_ws"], atol=ws_atol), tag
+            assert para.bic == pytest.approx(float(f[f"u{i}_gold_bic"]), rel=bic_rel), tag
+        else:
+            # chr17 UTR 2 and chr19: the CURRENT reference itself no longer reproduces these committed files
+            # (trace_chr17 u1: alpha 832 vs 841, beta [45,40,30] vs [10,45,30], 99.5 % of the labels; trace_chr19 u0:
+            # beta [5,15] vs [5,10], 99.8 % of the labels) - they predate the code, so they
+            # stay a coarse check; the exact check for these two UTRs is test_full_pipeline_reference_stream
+            assert np.all(np.abs(para.alpha_arr - f[f"u{i}_gold_alpha_arr"]) <= 9), tag
+            assert np.mean(para.label_arr == f[f"u{i}_gold_label_arr"]) >= 0.99, tag
+            assert np.allclose(para.ws, f[f"u{i}_gold_ws"], atol=2e-2), tag
+            assert para.bic == pytest.approx(float(f[f"u{i}_gold_bic"]), rel=2e-2), tag
         assert np.array_equal(para.cb_id_arr, f[f"u{i}_gold_cb_id_arr"])
         assert np.array_equal(para.readID_arr, f[f"u{i}_gold_readID_arr"])
         assert len(para.label_arr) == len(para.readID_arr)
@@ -338,6 +357,10 @@ def test_c_abi_error_paths(hip_ctx):
     for j in bad:
         with pytest.raises(_lib.ScapeHipError):
             batch.em([j])
+    # more non-fixed jobs on one UTR than the M-step's per-tile job table holds (SCAPE_MAX_JOBS_PER_UTR = 1024)
+    with pytest.raises(_lib.ScapeHipError, match="more than 1024"):
+        batch.em([good] * 1025)
+    assert len(batch.em([good] * 1024)) == 1024             # the limit itself is fine
     assert batch.em([good])[0].K == 2                       # context still usable after errors
     with pytest.raises(_lib.ScapeHipError):
         _lib.Context(device=99)
@@ -527,6 +550,56 @@ def test_config2_full_size_every_utr_vs_cpu_port(oracle):
     assert bench.parity_count(preps, plan, res, outs) == U
     for (fit, lab, nj), q in zip(res, preps):
         assert 1 <= fit.K <= 5 and len(lab) == q.N and abs(fit.ws.sum() - 1) < 1e-12
+
+
+def test_headline_shape_every_utr_vs_cpu_port(oracle):
+    """BASELINE config #3 (the headline) shape: 64 UTRs x 2,000 reads, K = 1..10 x 10 restarts = 6,400 EM jobs in
+    one resident batch through Engine.process; the CPU port (oracle) runs the same 100 jobs of EVERY UTR and goes
+    through the reference's selection and pruning rule; all 64 pA calls must agree (K, alpha, beta; ws to 1e-4
+    where no re-fit is involved)."""
+    import bench
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    U, kw = 64, dict(n_max_apa=10, n_min_apa=1)
+    preps = []
+    for i in range(U):
+        g, df, _ = synth_utr(i, 2000, k_cap=10, base_seed=20250225)      # the bench's own stream
+        preps.append(prepare_utr(df, gene_info_str=g, **kw))
+    eng = Engine()
+    plan = eng.plan(preps, [(20250225 + i) % 2 ** 32 for i in range(U)])
+    assert len(plan["main"]) == 100 * U and plan["main"].kmax == 10
+    batch = eng.load(preps)
+    res = eng.process(batch, preps, plan, re_run_mode=False)
+    cores = min(16, os.cpu_count() or 1)
+    cb, outs = bench.cpu_baseline(preps, plan, 1e9, cores)          # target time = infinity: every UTR
+    assert len(outs) == U
+    assert bench.parity_count(preps, plan, res, outs) == U
+    for (fit, lab, nj), q in zip(res, preps):
+        assert 1 <= fit.K <= 10 and len(lab) == q.N and abs(fit.ws.sum() - 1) < 1e-12
+    batch.free()
+
+
+def test_mstep_byte_tally_is_consistent(hip_ctx):
+    """scape_hip_em_traffic: the M-step's own byte count of a sweep is positive, at most one pass over the
+    tensor per launch, and the v bytes counted once never exceed the v bytes requested."""
+    from scape_amd.engine import Engine, HipBatch
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    kw = dict(n_max_apa=5, n_min_apa=1)
+    preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df, _ in (synth_utr(i, 800, k_cap=5, base_seed=31) for i in range(12))]
+    batch = HipBatch(hip_ctx, preps)
+    batch.build()
+    plan = Engine.plan(preps, list(range(12)))
+    batch.em_packed(plan["main"])
+    tr = batch.em_traffic()
+    tensor = 8 * sum(q.T * len(q.betas) * ((q.N + 15) // 16 * 16) for q in preps)
+    assert 1 <= tr["launches"] <= 50
+    assert 0 < tr["tensor_bytes"] <= tensor * tr["launches"]
+    assert 0 < tr["v_bytes_unique"] <= tr["v_bytes_requested"]
+    rounds, slab, _z = batch.em_counters()
+    assert 8 * slab >= tr["tensor_bytes"]            # job-at-a-time reads at least what the shared stream reads
+    batch.free()
 
 
 def test_infer_files_reference_groups_equal_single_file_runs(tmp_path):
