@@ -75,6 +75,38 @@ struct DevParams {
 // ------------------------------------------------------------------------------------------
 // device functions: the reference's @ti.func set (taichi_core.py:24-97)
 // ------------------------------------------------------------------------------------------
+// log(x) for finite x > 0 (subnormals included) in ~35 f64 instructions instead of the ~85 of the library's
+// double-double routine - the tensor build takes one log per entry (13 x N x T per UTR) and is bound by them.
+// Algorithm: the classic argument reduction x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2), s = f/(2+f),
+// log(1+f) = f - hfsq + s (hfsq + R(s^2)) with the degree-14 minimax R in s (coefficients Lg1..Lg7, error < 2^-58.45),
+// k ln2 added as a hi/lo pair; the quotient comes from v_rcp_f64 plus two Newton steps and a residual correction.
+// Worst error found on 2e7 arguments (host replica of exactly this sequence, against long-double log): 0.83 ulp.
+__device__ __forceinline__ double d_log_pos(double x) {
+#pragma clang fp contract(off)
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m * 2.0 : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0, d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    double s = f * r;
+    s = __builtin_fma(__builtin_fma(-d, s, f), r, s);
+    const double dk = (double)e, z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double inner = __builtin_fma(s, hfsq + R, dk * ln2_lo);
+    return dk * ln2_hi - ((hfsq - inner) - f);
+}
+
 __device__ __forceinline__ double d_logw(double w) { return (w <= 0.0) ? SENT : log(w); }
 __device__ __forceinline__ double d_logpdf_normal(double x, double mu, double sigma) {
     double z = (x - mu) / sigma;
@@ -102,7 +134,7 @@ __device__ __forceinline__ double d_point_r_unknown(double x, double l, double t
         for (int j = 0; j < S; ++j) v += 1 / s[j] * d_pdf_normal(x, th + s[j] - mu_f, sigma_f) * lk * pmf[j];
     }
     if (v < 1e-300) v = 0.0;
-    *a = (v <= 0.0) ? SENT : log(v);
+    *a = (v <= 0.0) ? SENT : d_log_pos(v);
     return v;
 }
 // loglik_xlr_t_r_known_kernel body (taichi_core.py:111-132), two-pass logsumexp (:40-54)
@@ -355,7 +387,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
             } else if (isnan(pa[d.bin_off + n]) && isnan(r[d.bin_off + n])) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (kq + 4 * q < B) Mi[(size_t)(kq + 4 * q) * d.Np + n] = (acc[q] > 0.0) ? log(acc[q]) : SENT;
+                    if (kq + 4 * q < B) Mi[(size_t)(kq + 4 * q) * d.Np + n] = (acc[q] > 0.0) ? d_log_pos(acc[q]) : SENT;
             }
         }
     } else if (!all_log) {
@@ -378,13 +410,13 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                 }
 #pragma unroll
                 for (int j = 0; j < BMAX; ++j)
-                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? log(acc[j]) : SENT;
+                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? d_log_pos(acc[j]) : SENT;
             } else {
                 for (int j = 0; j < B; ++j) {
                     double acc = 0.0;
                     for (int w = 0; w < Wall; ++w)
                         acc += Vu[(size_t)(lo_all + w) * d.Np + n] * p[(size_t)j * Wmax + w];
-                    Mi[(size_t)j * d.Np + n] = (acc > 0.0) ? log(acc) : SENT;
+                    Mi[(size_t)j * d.Np + n] = (acc > 0.0) ? d_log_pos(acc) : SENT;
                 }
             }
         }
@@ -408,7 +440,7 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
         }
         double sum = 0.0;
         for (int w = 0; w < W; ++w) sum += exp(Au[(size_t)(a + w) * d.Np + n] + gj[w] - Gj - mx);
-        Mi[(size_t)j * d.Np + n] = log(sum) + mx;
+        Mi[(size_t)j * d.Np + n] = d_log_pos(sum) + mx;
     }
 }
 
@@ -978,16 +1010,32 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         std::vector<int64_t> fill(ujoff.begin(), ujoff.end() - 1);
         for (size_t j = 0; j < nj; ++j) ujlist[fill[job_utr[j]]++] = (int32_t)j;
     }
-    size_t vtot = 0, pttot = 0;
+    // UTRs that have at least one job in this call, in index order: the M-step grid runs over this list, so a call
+    // that touches a few UTRs of a large resident batch (reference-stream mode) still uses every XCD
+    std::vector<int32_t> active;
+    for (int u = 0; u < c->n_utr; ++u)
+        if (ujoff[u + 1] > ujoff[u]) active.push_back(u);
+    const int n_active = (int)active.size();
+    int max_jobs_utr = 1;
+    for (int u : active) max_jobs_utr = std::max<int>(max_jobs_utr, (int)(ujoff[u + 1] - ujoff[u]));
     int tiles_max = 1;
+    for (int u : active) tiles_max = std::max(tiles_max, (c->h_desc[u].T * B + MT_ROWS - 1) / MT_ROWS);
+    // Small calls (the ~100 jobs of one UTR, or of a few streams' current UTRs) leave most of the GPU idle and an
+    // M-step round takes as long as ONE workgroup needs for its pass over a tile: the jobs of a tile are then cut
+    // into passes of 16 that separate workgroups take (k2_mstep).  Every score is the same MFMA chain either way,
+    // so a UTR's result does not depend on the size of the call it is part of.
+    const char *env_r = getenv("SCAPE_HIP_SPLIT_MAXTILES");
+    const int split_maxtiles = env_r ? atoi(env_r) : 1024;
+    const bool job_split = (long long)n_active * tiles_max <= split_maxtiles;
+    constexpr int pt_rows = MT_ROWS;
+    size_t vtot = 0, pttot = 0;
     for (size_t j = 0; j < nj; ++j) {
         const UtrDesc &d = c->h_desc[job_utr[j]];
-        const int nt = (d.T * B + MT_ROWS - 1) / MT_ROWS;
+        const int nt = (d.T * B + pt_rows - 1) / pt_rows;
         voff[j] = (int64_t)vtot;
         ptoff[j] = (int64_t)pttot;
         vtot += (size_t)d.Np;
         pttot += (size_t)nt;
-        tiles_max = std::max(tiles_max, nt);
     }
     if (c->e_ia.ensure(nj * kmax * 4) || c->e_ib.ensure(nj * kmax * 4) || c->e_sia.ensure(nj * kmax * 4) ||
         c->e_sib.ensure(nj * kmax * 4) || c->e_ws.ensure(nj * (kmax + 1) * 8) || c->e_slw.ensure(nj * (kmax + 1) * 8) ||
@@ -997,12 +1045,6 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         c->e_ptscore.ensure(pttot * 8) || c->e_ptrow.ensure(pttot * 4) || c->e_ptoff.ensure(nj * 8) ||
         c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4) || c->e_active.ensure((size_t)c->n_utr * 4))
         return 1;
-    // UTRs that have at least one job in this call, in index order: the M-step grid runs over this list, so a call
-    // that touches a few UTRs of a large resident batch (reference-stream mode) still uses every XCD
-    std::vector<int32_t> active;
-    for (int u = 0; u < c->n_utr; ++u)
-        if (ujoff[u + 1] > ujoff[u]) active.push_back(u);
-    const int n_active = (int)active.size();
     if (n_active) HIPCHK(hipMemcpyAsync(c->e_active.p, active.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->e_voff.p, voff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->e_ptoff.p, ptoff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
@@ -1118,14 +1160,14 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             if (r < nround && any_m) {
                 if (fine && ev_begin(c, 5)) return 1;
                 const int nu = g_a0[g + 1] - g_a0[g];
-                // few active UTRs: the GPU is mostly idle and a round's time is one workgroup's serial time, so the
-                // two 64-job passes of a tile with up to 128 jobs go to two workgroups
-                const unsigned psplit = (nu <= 64 && n_jobs / std::max(nu, 1) > MT_MAXJ) ? 2u : 1u;
+                // few live tiles: passes of 16 jobs, one workgroup each (gridDim.y covers the longest job list of a UTR)
+                const int jobs_per_pass = job_split ? 16 : MT_MAXJ;
+                const unsigned psplit = job_split ? (unsigned)std::min(64, (max_jobs_utr + 15) / 16) : 1u;
                 hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max), psplit), dim3(256), 0, st,
                                    c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, tiles_max,
                                    c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo,
                                    S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row,
-                                   c->d_tile_nend.as<int32_t>(), c->d_counters.as<unsigned long long>(), dbg);
+                                   c->d_tile_nend.as<int32_t>(), c->d_counters.as<unsigned long long>(), jobs_per_pass, dbg);
                 c->h_traffic[3] += 1;
                 HIPCHK(hipGetLastError());
                 if (fine && ev_end(c, 5)) return 1;

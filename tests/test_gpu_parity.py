@@ -580,6 +580,40 @@ def test_headline_shape_every_utr_vs_cpu_port(oracle):
     batch.free()
 
 
+def test_small_call_shapes_give_identical_bits(hip_ctx):
+    """Calls with few live tensor tiles run the M-step in its low-latency shape (the jobs of a tile cut into passes
+    of 16 for separate workgroups, tiles dealt over all XCDs); large calls run one workgroup per tile and 64 jobs.
+    The same jobs through both must agree bit for bit (a UTR's result must not depend on what else shares the
+    launch) - K <= 3 (the 4-column E-step kernel), K = 1..10 (12-column kernel, every exact variant), K = 12..14."""
+    from scape_amd.engine import Engine, HipBatch
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    for kcap, kmin, reads, n_utr in ((3, 1, 300, 3), (10, 1, 1500, 2), (14, 12, 700, 1)):
+        kw = dict(n_max_apa=kcap, n_min_apa=kmin)
+        preps = [prepare_utr(df, gene_info_str=g, **kw)
+                 for g, df, _ in (synth_utr(i, reads, k_cap=5, base_seed=4100 + kcap) for i in range(n_utr))]
+        batch = HipBatch(hip_ctx, preps)
+        batch.build()
+        plan = Engine.plan(preps, [11 + i for i in range(n_utr)])
+        outs = {}
+        for name, split in (("throughput", "0"), ("low_latency", "1000000")):
+            os.environ["SCAPE_HIP_SPLIT_MAXTILES"] = split
+            try:
+                outs[name] = [a.copy() for a in batch.em_packed(plan["main"])]
+            finally:
+                del os.environ["SCAPE_HIP_SPLIT_MAXTILES"]
+        ref, got = outs["throughput"], outs["low_latency"]
+        nlb = ref[4]
+        assert nlb.min() >= 2
+        for x, y, what in zip(ref, got, ("alpha", "beta", "ws", "bic", "n_lb", "lb")):
+            if what == "lb":
+                mask = np.arange(x.shape[1])[None, :] < nlb[:, None]
+                assert np.array_equal(x[mask], y[mask]), (kcap, what)
+            else:
+                assert np.array_equal(x, y), (kcap, what)
+        batch.free()
+
+
 def test_mstep_byte_tally_is_consistent(hip_ctx):
     """scape_hip_em_traffic: the M-step's own byte count of a sweep is positive, at most one pass over the
     tensor per launch, and the v bytes counted once never exceed the v bytes requested."""
