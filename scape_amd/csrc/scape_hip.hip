@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                                                  const double *__restrict__ AT,
                                                  const double *__restrict__ V,
                                                  double *__restrict__ M, int Wmax, int all_log,
-                                                 int *__restrict__ err_flag, int n_utr, int T_max, int probe) {
+                                                 int *__restrict__ err_flag, int n_utr, int T_max,
+                                                 int32_t *__restrict__ tile_nend, int probe) {
     extern __shared__ double sm[];
     // blocks b and b+8 share an XCD: all grid points of a UTR go to one XCD so its V rows (each is
     // read by ~43 neighbouring alphas) are fetched into one L2 only.  Placement only affects speed.
@@ -352,6 +353,19 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
     }
 
     double *Mi = M + (size_t)d.m_off + (size_t)i * B * d.Np;
+    // Tile extents (used by the M-step, em_lockstep.inc): bins are ordered by read start, so each tensor row is finite
+    // on a prefix of the bins and holds the sentinel (read impossible) on the rest - 35-50 % of all entries.  For
+    // every TILE_ROWS-row tile the table gets one past the last bin that is finite in ANY of its rows (rounded up to
+    // 16): beyond it every row of the tile is the sentinel, and the M-step replaces that part of the dot product by
+    // SENT * sum(v) instead of streaming it.  The rows of this workgroup lie in at most two tiles.
+    const int tile0 = (i * B) / TILE_ROWS, j_split = (tile0 + 1) * TILE_ROWS - i * B;   // rows j >= j_split: tile0 + 1
+    int fin0 = 0, fin1 = 0;
+    auto note = [&](int j, int n, double val) {
+        if (val != SENT) {
+            if (j < j_split) fin0 = max(fin0, n + 1);
+            else fin1 = max(fin1, n + 1);
+        }
+    };
     // ---- linear-domain path -----------------------------------------------------------------
     // out[j][n] = sum_w p[j][w] * V[w][n] is a [16 x W] x [W x N] product: on the f64 matrix cores one
     // v_mfma_f64_16x16x4_f64 covers 16 betas (13 used) x 16 bins x 4 taps.  A = weights from LDS (lane l:
@@ -387,7 +401,11 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
             } else if (isnan(pa[d.bin_off + n]) && isnan(r[d.bin_off + n])) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (kq + 4 * q < B) Mi[(size_t)(kq + 4 * q) * d.Np + n] = (acc[q] > 0.0) ? d_log_pos(acc[q]) : SENT;
+                    if (kq + 4 * q < B) {
+                        const double val = (acc[q] > 0.0) ? d_log_pos(acc[q]) : SENT;
+                        Mi[(size_t)(kq + 4 * q) * d.Np + n] = val;
+                        note(kq + 4 * q, n, val);
+                    }
             }
         }
     } else if (!all_log) {
@@ -410,13 +428,19 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                 }
 #pragma unroll
                 for (int j = 0; j < BMAX; ++j)
-                    if (j < B) Mi[(size_t)j * d.Np + n] = (acc[j] > 0.0) ? d_log_pos(acc[j]) : SENT;
+                    if (j < B) {
+                        const double val = (acc[j] > 0.0) ? d_log_pos(acc[j]) : SENT;
+                        Mi[(size_t)j * d.Np + n] = val;
+                        note(j, n, val);
+                    }
             } else {
                 for (int j = 0; j < B; ++j) {
                     double acc = 0.0;
                     for (int w = 0; w < Wall; ++w)
                         acc += Vu[(size_t)(lo_all + w) * d.Np + n] * p[(size_t)j * Wmax + w];
-                    Mi[(size_t)j * d.Np + n] = (acc > 0.0) ? d_log_pos(acc) : SENT;
+                    const double val = (acc > 0.0) ? d_log_pos(acc) : SENT;
+                    Mi[(size_t)j * d.Np + n] = val;
+                    note(j, n, val);
                 }
             }
         }
@@ -440,46 +464,27 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
         }
         double sum = 0.0;
         for (int w = 0; w < W; ++w) sum += exp(Au[(size_t)(a + w) * d.Np + n] + gj[w] - Gj - mx);
-        Mi[(size_t)j * d.Np + n] = d_log_pos(sum) + mx;
+        const double val = d_log_pos(sum) + mx;
+        Mi[(size_t)j * d.Np + n] = val;
+        note(j, n, val);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Tile extents: bins are ordered by read start, so each tensor row (theta_a, beta_b) is finite on a
-// prefix of the bins and holds the sentinel (read impossible: x + l > theta) on the rest - 35-50 % of
-// all entries.  For every 64-row tile this records one past the last bin that is finite in ANY of its
-// rows (rounded up to 16).  Beyond it every row of the tile is the sentinel, and the M-step replaces
-// that part of the dot product by SENT * sum(v) instead of streaming it.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_extent(const UtrDesc *__restrict__ descs, int B,
-                                                     const double *__restrict__ M,
-                                                     int32_t *__restrict__ tile_nend) {
-    __shared__ int s_max;
-    const UtrDesc d = descs[blockIdx.y];
-    const int nrows = d.T * B, row0 = blockIdx.x * TILE_ROWS;
-    if (row0 >= nrows) return;
-    if (threadIdx.x == 0) s_max = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int best = 0;
-    for (int rr = wave; rr < TILE_ROWS; rr += 4) {
-        const int row = row0 + rr;
-        if (row >= nrows) break;
-        const double *Mr = M + (size_t)d.m_off + (size_t)row * d.Np;
-        for (int base = ((d.N - 1) / 64) * 64; base >= 0; base -= 64) {   // scan from the end
-            const int n = base + lane;
-            const bool fin = (n < d.N) && (Mr[n] != SENT);
-            const unsigned long long m = __ballot(fin);
-            if (m) {
-                best = max(best, base + 64 - (int)__builtin_clzll(m));
-                break;
-            }
-            if (base + 64 <= best) break;   // cannot improve on what another row already found
+    if (tile_nend) {
+        __shared__ int s_fin[2];
+        if (tid < 2) s_fin[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            fin0 = max(fin0, __shfl_xor(fin0, off, 64));
+            fin1 = max(fin1, __shfl_xor(fin1, off, 64));
         }
+        if ((tid & 63) == 0) {
+            atomicMax(&s_fin[0], fin0);
+            atomicMax(&s_fin[1], fin1);
+        }
+        __syncthreads();
+        if (tid < 2 && s_fin[tid] > 0)
+            atomicMax(&tile_nend[d.tile_off + tile0 + tid], min(d.Np, (s_fin[tid] + 15) & ~15));
     }
-    if (lane == 0) atomicMax(&s_max, best);
-    __syncthreads();
-    if (threadIdx.x == 0) tile_nend[d.tile_off + blockIdx.x] = min(d.Np, (s_max + 15) & ~15);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -970,7 +975,7 @@ static int max_window(const double *th, int T, double beta) {
 static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int T_max, int Wmax,
                           const UtrDesc *d_desc, const double *d_r, const double *d_pa,
                           const double *d_theta, const int32_t *d_loglist, const double *d_AT,
-                          const double *d_V, double *d_M, int all_log) {
+                          const double *d_V, double *d_M, int all_log, int32_t *d_tile_nend) {
     if (c->d_err.ensure(sizeof(int))) return 1;
     HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
     const size_t lds = ((size_t)2 * prm.B * Wmax + prm.B) * sizeof(double) + (size_t)2 * (prm.B + 1) * sizeof(int) +
@@ -981,10 +986,10 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
     const int probe = pe ? atoi(pe) : 0;
     if (prm.B <= 16)
         hipLaunchKernelGGL(k_phase_b<16>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, probe);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, d_tile_nend, probe);
     else
         hipLaunchKernelGGL(k_phase_b<1>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
-                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, probe);
+                           d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, d_tile_nend, probe);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1386,7 +1391,7 @@ int scape_hip_get_loglik_marginal_tensor(scape_hip_ctx *c, const double *all_the
         return fail(std::string("upload: ") + hipGetErrorString(e));
     }
     rc = launch_phase_b(c, P, 1, T, Wmax, ddesc.as<UtrDesc>(), nullptr, nullptr, dth.as<double>(), nullptr,
-                        dAT.as<double>(), nullptr, dM.as<double>(), 1);
+                        dAT.as<double>(), nullptr, dM.as<double>(), 1, nullptr);
     if (!rc) rc = check_err_flag(c, "get_loglik_marginal_tensor");
     if (!rc) {
         e = hipMemcpy2DAsync(out, (size_t)N * sizeof(double), dM.p, (size_t)Np * sizeof(double),
@@ -1505,13 +1510,11 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
     HIPCHK(hipGetLastError());
     if (ev_end(c, 0)) return 1;
     if (ev_begin(c, 1)) return 1;
+    HIPCHK(hipMemsetAsync(c->d_tile_nend.p, 0, c->tiles_total * 4, c->stream));   // Phase B raises the extents by atomicMax
     if (launch_phase_b(c, c->prm, c->n_utr, c->T_max, c->W_max, c->d_desc.as<UtrDesc>(), c->d_r.as<double>(),
                        c->d_pa.as<double>(), c->d_theta.as<double>(), c->d_loglist.as<int32_t>(),
-                       c->d_AT.as<double>(), c->d_V.as<double>(), c->d_M.as<double>(), 0))
+                       c->d_AT.as<double>(), c->d_V.as<double>(), c->d_M.as<double>(), 0, c->d_tile_nend.as<int32_t>()))
         return 1;
-    hipLaunchKernelGGL(k_tile_extent, dim3(c->tiles_max_all, c->n_utr), dim3(256), 0, c->stream, c->d_desc.as<UtrDesc>(),
-                       c->prm.B, c->d_M.as<double>(), c->d_tile_nend.as<int32_t>());
-    HIPCHK(hipGetLastError());
     if (ev_end(c, 1)) return 1;
     if (check_err_flag(c, "batch_build")) return 1;
     c->built = true;

@@ -14,9 +14,10 @@ from scape_amd.synth import synth_utr        # noqa: E402
 
 kw = dict(n_max_apa=10, n_min_apa=1)
 files = []
-for f in range(8):
+NF = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for f in range(NF):
     preps = []
-    for i in range(32):
+    for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 32):
         g, df, _ = synth_utr(f * 32 + i, 2000, k_cap=10, base_seed=20250225)
         preps.append(prepare_utr(df, gene_info_str=g, **kw))
     files.append(preps)
