@@ -107,6 +107,29 @@ __device__ __forceinline__ double d_log_pos(double x) {
     return dk * ln2_hi - ((hfsq - inner) - f);
 }
 
+#include "exp_table.inc"
+// exp(x) for x <= 0 in ~18 f64 instructions + one 16-byte LDS read (the library routine takes ~37): the E-step
+// takes one exp per (bin, component, round), Phase A thirteen per (bin, theta) - both are bound by them.
+// x = (128 e + j) ln2/128 + r, |r| <= ln2/256: exp(x) = 2^e * T[j] * (1 + p(r)), T[j] = 2^(j/128) as a hi/lo pair
+// (table in LDS: d_load_exptab), p = expm1 to degree 5 (next term r^6/720 < 2^-62).  Arguments below -750 give 0
+// like exp itself.  Worst error on 3e7 arguments in [-700, 0] (host replica, against long-double exp): 0.60 ulp.
+__device__ __forceinline__ void d_load_exptab(double2 *tab /* LDS, 128 entries */, int tid, int nthreads) {
+    for (int i = tid; i < 128; i += nthreads) tab[i] = g_exp_tab[i];
+}
+__device__ __forceinline__ double d_exp_nonpos(double x, const double2 *tab) {
+#pragma clang fp contract(off)
+    x = fmax(x, -750.0);
+    const double n = __builtin_rint(x * EXP_INV_L);
+    double r = __builtin_fma(n, -EXP_L_HI, x);
+    r = __builtin_fma(n, -EXP_L_LO, r);
+    const int ni = (int)n;
+    const double2 t = tab[ni & 127];
+    const double r2 = r * r;
+    const double q = __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, 1.0 / 120, 1.0 / 24), 1.0 / 6), 0.5);
+    const double p = __builtin_fma(r2, q, r);
+    return ldexp(t.x + __builtin_fma(t.x, p, t.y), ni >> 7);
+}
+
 __device__ __forceinline__ double d_logw(double w) { return (w <= 0.0) ? SENT : log(w); }
 __device__ __forceinline__ double d_logpdf_normal(double x, double mu, double sigma) {
     double z = (x - mu) / sigma;
@@ -115,6 +138,11 @@ __device__ __forceinline__ double d_logpdf_normal(double x, double mu, double si
 __device__ __forceinline__ double d_pdf_normal(double x, double mu, double sigma) {
     double z = (x - mu) / sigma;
     return exp(-0.5 * (z * z)) / sqrt(2 * PI_REF) / sigma;
+}
+
+__device__ __forceinline__ double d_pdf_normal_t(double x, double mu, double sigma, const double2 *tab) {
+    double z = (x - mu) / sigma;
+    return d_exp_nonpos(-0.5 * (z * z), tab) / sqrt(2 * PI_REF) / sigma;
 }
 
 // loglik_xlr_t_pa_kernel body (taichi_core.py:101-107)
@@ -126,12 +154,12 @@ __device__ __forceinline__ double d_point_pa(double x, double l, double pa, doub
 // loglik_xlr_t_r_unknown_kernel body (taichi_core.py:141-157); returns v (linear), A through *a
 __device__ __forceinline__ double d_point_r_unknown(double x, double l, double th, const double *s,
                                                     const double *pmf, int S, double mu_f,
-                                                    double sigma_f, double *a) {
+                                                    double sigma_f, double *a, const double2 *tab) {
     double u = th - x;
     double v = 0.0;
     if (l <= u) {  // lik_l_xt == 0 otherwise, every term of the sum is then exactly 0
         double lk = 1 / u;
-        for (int j = 0; j < S; ++j) v += 1 / s[j] * d_pdf_normal(x, th + s[j] - mu_f, sigma_f) * lk * pmf[j];
+        for (int j = 0; j < S; ++j) v += 1 / s[j] * d_pdf_normal_t(x, th + s[j] - mu_f, sigma_f, tab) * lk * pmf[j];
     }
     if (v < 1e-300) v = 0.0;
     *a = (v <= 0.0) ? SENT : d_log_pos(v);
@@ -221,10 +249,13 @@ __global__ void k_op_r_known(const double *x, const double *l, const double *r, 
 }
 __global__ void k_op_r_unknown(const double *x, const double *l, int n, DevParams P, double theta,
                                double *out) {
+    __shared__ double2 s_exptab[128];
+    d_load_exptab(s_exptab, threadIdx.x, blockDim.x);
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         double a;
-        d_point_r_unknown(x[i], l[i], theta, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a);
+        d_point_r_unknown(x[i], l[i], theta, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
         out[i] = a;
     }
 }
@@ -240,6 +271,9 @@ __global__ __launch_bounds__(256) void k_phase_a(const UtrDesc *__restrict__ des
                                                  const double *__restrict__ pa,
                                                  const double *__restrict__ theta,
                                                  double *__restrict__ AT, double *__restrict__ V) {
+    __shared__ double2 s_exptab[128];
+    d_load_exptab(s_exptab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const UtrDesc d = descs[blockIdx.z];
     const int t = blockIdx.y;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,7 +293,7 @@ __global__ __launch_bounds__(256) void k_phase_a(const UtrDesc *__restrict__ des
     } else if (!isnan(rn)) {
         a = d_point_r_known(xn, ln, rn, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f);
     } else {
-        v = d_point_r_unknown(xn, ln, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a);
+        v = d_point_r_unknown(xn, ln, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
     }
     AT[o] = a;
     V[o] = v;
@@ -779,6 +813,9 @@ __global__ __launch_bounds__(256) void k_labels(const UtrDesc *__restrict__ desc
                                                 const int32_t *__restrict__ b_in,
                                                 const double *__restrict__ ws_in,
                                                 int32_t *__restrict__ labels) {
+    __shared__ double2 s_exptab[128];
+    d_load_exptab(s_exptab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const int sel = blockIdx.x;
     const UtrDesc d = descs[sel_utr[sel]];
     const int K = sel_K[sel], C = K + 1, B = P.B;
@@ -803,7 +840,7 @@ __global__ __launch_bounds__(256) void k_labels(const UtrDesc *__restrict__ desc
             }
         }
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) z[c] = (c < C) ? exp((lz[c] - mx) * cn) : 0.0;
+        for (int c = 0; c < CMAX; ++c) z[c] = (c < C) ? d_exp_nonpos((lz[c] - mx) * cn, s_exptab) : 0.0;
         const double s = d_np_sum<CMAX>(z, C);
         int best = 0;
         double bz = 0.0;
