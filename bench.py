@@ -54,7 +54,7 @@ def parse():
                          "default = the whole headline job")
     ap.add_argument("--e2e-ref-utrs", type=int, default=16384,
                     help="UTRs of the end-to-end leg in the exact reference-stream mode (a prefix of the same files)")
-    ap.add_argument("--e2e-multi-utrs", type=int, default=2048,
+    ap.add_argument("--e2e-multi-utrs", type=int, default=1024,
                     help="N > 1: UTRs PER GPU of the multi-GPU end-to-end leg (infer_all(gpus=N) on chunk files of "
                          "BASELINE config #4's shape), 0 = skip")
     ap.add_argument("--e2e-multi-reads", type=int, default=10000)
@@ -283,7 +283,11 @@ def end_to_end_multi(args, pool, gpus):
         dt = time.perf_counter() - t0
         outs = [os.path.join(root, "pkl_output", os.path.basename(f)[:-10] + ".res.pkl") for f in files]
         assert all(os.path.exists(o) for o in outs), "a chunk has no result file"
+        busy = max((w.get("wall_s", 0.0) for w in st.get("workers") or []), default=0.0)
         return dict(value=n_utrs / dt, unit="UTRs/s", n_gpus=gpus, utrs=n_utrs, seconds=dt,
+                    value_excl_worker_startup=(n_utrs / busy) if busy else None, slowest_worker_s=busy,
+                    note="seconds includes starting the worker processes (python + numpy imports, HIP context, device "
+                         "buffers: ~2 s); slowest_worker_s is the longest worker's own pipeline time",
                     workload=f"{n_utrs} synthetic UTRs x {args.e2e_multi_reads} reads, K=1..{args.kcap} "
                              f"(BASELINE config #4 shape), {len(files)} chunk files -> .res.pkl, rng_mode per_utr",
                     chunk_files=len(files), input_bytes=in_bytes, synth_write_s=t_write,
