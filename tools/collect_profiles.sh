@@ -3,7 +3,7 @@
 # writes profiles/<tag>_kernel_stats.csv and profiles/<tag>_pmc_<counter>.csv (+ raw output under gpurun_out/<tag>/)
 set -e -o pipefail
 TAG=${1:?tag}; shift || true
-ROOT=$(pwd)
+ROOT=$(pwd)   # summaries are also written under gpurun_out/<tag>/ (gpurun merges only gpurun_out/ back)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 export TMPDIR=/tmp
@@ -17,4 +17,5 @@ for C in "$@"; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" $ARGS1 > "$OUT/pmc_$N.json" 2> "$OUT/pmc_$N.err" )
   python3 tools/rocprof_summary.py pmc "$OUT/pmc_$N" "profiles/${TAG}_pmc_${N}.csv" "python3 bench.py $ARGS1"
 done
+cp profiles/${TAG}_* "$OUT/" 2>/dev/null || true
 head -8 "profiles/${TAG}_kernel_stats.csv"

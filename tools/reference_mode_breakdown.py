@@ -12,7 +12,8 @@ from scape_amd.synth import synth_utr        # noqa: E402
 
 kw = dict(n_max_apa=10, n_min_apa=1)
 preps = []
-for i in range(32):
+NU = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+for i in range(NU):
     g, df, _ = synth_utr(i, 2000, k_cap=10, base_seed=20250225)
     preps.append(prepare_utr(df, gene_info_str=g, **kw))
 eng = Engine(0)
