@@ -100,7 +100,9 @@ int scape_hip_batch_load(scape_hip_ctx *ctx, const scape_hip_params *params, int
 /* device bytes the loaded batch needs / the device offers (for sizing waves on the host) */
 int scape_hip_batch_bytes(scape_hip_ctx *ctx, int64_t *bytes_batch, int64_t *bytes_free,
                           int64_t *bytes_total);
-/* Phase A (apa_core.py:954-957) then Phase B (apa_core.py:959) for every UTR of the batch */
+/* Phase A (apa_core.py:954-957) then Phase B (apa_core.py:959) for every UTR of the batch.  The kernels are queued,
+   not awaited: the next call on the context runs behind them, and a device-side consistency failure of the build is
+   reported by that call (batch_em / batch_labels / batch_fetch_*). */
 int scape_hip_batch_build(scape_hip_ctx *ctx);
 /*
  * n_jobs em_algo calls (apa_core.py:714-779).  Job j works on UTR job_utr[j] with job_K[j]

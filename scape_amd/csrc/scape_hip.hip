@@ -906,6 +906,7 @@ struct scape_hip_ctx {
     char name[256] = {0};
     DevParams prm;
     bool loaded = false, built = false;
+    bool build_unchecked = false;     // Phase A/B are queued, their device-side consistency flag has not been read yet
     int n_utr = 0, T_max = 0, Np_max = 0, W_max = 1;
     int64_t n_bins = 0;
     std::vector<UtrDesc> h_desc;
@@ -1028,6 +1029,18 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
         hipLaunchKernelGGL(k_phase_b<1>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
                            d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, d_tile_nend, probe);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int check_err_flag(scape_hip_ctx *c, const char *what);
+// reads the consistency flag of a queued batch_build (synchronises the stream)
+static int finish_build(scape_hip_ctx *c) {
+    if (!c->build_unchecked) return 0;
+    c->build_unchecked = false;
+    if (check_err_flag(c, "batch_build")) {
+        c->built = false;
+        return 1;
+    }
     return 0;
 }
 
@@ -1292,7 +1305,7 @@ int scape_hip_batch_free(scape_hip_ctx *c) {
                      &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_rdn0, &c->e_rdn1, &c->e_V, &c->e_Vsuf, &c->e_voff, &c->e_ptscore,
                      &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist, &c->e_active};
     for (DevBuf *b : all) b->release();
-    c->loaded = c->built = false;
+    c->loaded = c->built = c->build_unchecked = false;
     c->n_utr = 0;
     return 0;
 }
@@ -1453,7 +1466,8 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
     if (!bin_off || !x || !l || !r || !pa || !cnt || !theta_off || !all_theta || !utr_L || !min_theta || !unif_ll)
         return fail("NULL array argument");
     CTX_ENTER(c);
-    c->loaded = c->built = false;
+    HIPCHK(hipStreamSynchronize(c->stream));   // a queued build of the previous batch still reads its buffers
+    c->loaded = c->built = c->build_unchecked = false;
     fill_params(c->prm, p->mu_f, p->sigma_f, p->max_unif_ws, p->n_beta, p->betas, p->n_s, p->s_dis, p->pmf_s, p->nround);
     double bmax = p->betas[0];
     for (int j = 1; j < p->n_beta; ++j) bmax = std::max(bmax, p->betas[j]);
@@ -1553,8 +1567,12 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
                        c->d_AT.as<double>(), c->d_V.as<double>(), c->d_M.as<double>(), 0, c->d_tile_nend.as<int32_t>()))
         return 1;
     if (ev_end(c, 1)) return 1;
-    if (check_err_flag(c, "batch_build")) return 1;
+    // The kernels are only queued here: the caller's next call (normally scape_hip_batch_em, whose host-side table
+    // checks then run while the GPU builds the tensors) launches behind them on the same stream, and reads the
+    // consistency flag at its own synchronisation point.  SCAPE_HIP_SYNC_BUILD restores the synchronous behaviour.
+    c->build_unchecked = true;
     c->built = true;
+    if (getenv("SCAPE_HIP_SYNC_BUILD") && finish_build(c)) return 1;
     return 0;
 }
 
@@ -1644,6 +1662,7 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     unsigned long long hc[N_COUNTERS];
     HIPCHK(hipMemcpyAsync(hc, c->d_counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (finish_build(c)) return 1;        // a batch_build queued before this call: its flag is final now
     for (int i = 0; i < 3; ++i) c->h_counters[i] = hc[i];
     c->h_traffic[0] = c->h_traffic[1] = c->h_traffic[2] = 0;
     for (int i = 0; i < 64; ++i) {
@@ -1714,6 +1733,7 @@ int scape_hip_batch_labels(scape_hip_ctx *c, int32_t n_sel, int32_t kmax, const 
         }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (finish_build(c)) return 1;
     return 0;
 }
 
@@ -1722,6 +1742,7 @@ int scape_hip_batch_fetch_loglik(scape_hip_ctx *c, int32_t utr, double *A_out) {
     if (!c->built) return fail("batch_build has not run");
     if (utr < 0 || utr >= c->n_utr) return fail("bad UTR index");
     CTX_ENTER(c);
+    if (finish_build(c)) return 1;
     const UtrDesc &d = c->h_desc[utr];
     std::vector<double> at((size_t)d.T * d.Np);
     HIPCHK(hipMemcpy(at.data(), c->d_AT.as<double>() + d.at_off, at.size() * 8, hipMemcpyDeviceToHost));
@@ -1735,6 +1756,7 @@ int scape_hip_batch_fetch_tensor(scape_hip_ctx *c, int32_t utr, double *M_out) {
     if (!c->built) return fail("batch_build has not run");
     if (utr < 0 || utr >= c->n_utr) return fail("bad UTR index");
     CTX_ENTER(c);
+    if (finish_build(c)) return 1;
     const UtrDesc &d = c->h_desc[utr];
     HIPCHK(hipMemcpy2D(M_out, (size_t)d.N * 8, c->d_M.as<double>() + d.m_off, (size_t)d.Np * 8, (size_t)d.N * 8,
                        (size_t)d.T * c->prm.B, hipMemcpyDeviceToHost));

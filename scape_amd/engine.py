@@ -636,9 +636,9 @@ class Engine:
         pj, spans = plan["main"], plan["spans"]
         # engines that share a device take turns for the long kernels (two EM sweeps at once only slow each
         # other down); uploads, host-side selection and the short re-fit launches overlap freely
-        batch.build()            # Phase A/B (VALU / matrix-core work) may overlap the other engine's HBM-bound sweep
+        ms0 = batch.timing(2)[0]          # (synchronises: read before the build is queued, not between build and EM)
+        batch.build()            # queued, not awaited: the EM call's host-side table checks run while the GPU builds
         with (self.sweep_lock if self.sweep_lock is not None else contextlib.nullcontext()):
-            ms0 = batch.timing(2)[0]
             out = batch.em_packed(pj, reuse_buffers=True)
             self.last_main_em_ms = batch.timing(2)[0] - ms0          # HIP-event time of the sweep launch
         self.last_main_counters = batch.em_counters()
