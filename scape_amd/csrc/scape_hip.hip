@@ -1079,8 +1079,9 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     // M-step round takes as long as ONE workgroup needs for its pass over a tile: the jobs of a tile are then cut
     // into passes of 16 that separate workgroups take (k2_mstep).  Every score is the same MFMA chain either way,
     // so a UTR's result does not depend on the size of the call it is part of.
-    const char *env_r = getenv("SCAPE_HIP_SPLIT_MAXTILES");
-    const int split_maxtiles = env_r ? atoi(env_r) : 1024;
+    const char *env_r = getenv("SCAPE_HIP_SPLIT_MAXTILES"), *env_w = getenv("SCAPE_HIP_WIDE_MAXJOBS");
+    const int split_maxtiles = env_r ? atoi(env_r) : 1024, wide_maxjobs = env_w ? atoi(env_w) : 1024;
+    const bool wide = n_jobs <= wide_maxjobs && kmax + 1 <= 16;   // E-step: 4 wavefronts per job (k2_estep_cs)
     const bool job_split = (long long)n_active * tiles_max <= split_maxtiles;
     constexpr int pt_rows = MT_ROWS;
     size_t vtot = 0, pttot = 0;
@@ -1195,20 +1196,25 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             hipStream_t st = g_stream[g];
             const int32_t *jl = c->e_ujlist.as<int32_t>() + j0;
             if (fine && ev_begin(c, 4)) return 1;
-#define LAUNCH_E(CM)                                                                                           \
-    hipLaunchKernelGGL(k2_estep<CM>, dim3((unsigned)(((ngj + 7) / 8) * 8)), dim3(64), 0, st,                   \
+#define LAUNCH_E(KERNEL, CM, THREADS)                                                                          \
+    hipLaunchKernelGGL(KERNEL<CM>, dim3((unsigned)(((ngj + 7) / 8) * 8)), dim3(THREADS), 0, st,                \
                        c->d_desc.as<UtrDesc>(), c->prm, c->d_cnt.as<double>(), c->d_M.as<double>(), kmax,      \
                        c->j_utr.as<int32_t>(), c->j_K.as<int32_t>(), c->j_fixed.as<int32_t>(),                 \
                        c->j_a.as<int32_t>(), c->j_b.as<int32_t>(), c->j_ws.as<double>(), c->j_karr.as<int8_t>(), \
                        S, c->j_ao.as<int32_t>(), c->j_bo.as<int32_t>(), c->j_wso.as<double>(),                 \
                        c->j_bic.as<double>(), c->j_nlb.as<int32_t>(), c->j_lb.as<double>(),                    \
                        c->d_counters.as<unsigned long long>(), r, jl, ngj)
-            if (kmax + 1 <= 4) LAUNCH_E(4);
-            else if (kmax + 1 <= 8) LAUNCH_E(8);
-            else if (kmax + 1 <= 12) LAUNCH_E(12);
-            else if (kmax + 1 <= 16) LAUNCH_E(16);
-            else if (kmax + 1 <= 24) LAUNCH_E(24);
-            else LAUNCH_E(32);
+            if (wide) {
+                if (kmax + 1 <= 4) LAUNCH_E(k2_estep_cs, 4, 256);
+                else if (kmax + 1 <= 8) LAUNCH_E(k2_estep_cs, 8, 256);
+                else if (kmax + 1 <= 12) LAUNCH_E(k2_estep_cs, 12, 256);
+                else LAUNCH_E(k2_estep_cs, 16, 256);
+            } else if (kmax + 1 <= 4) LAUNCH_E(k2_estep, 4, 64);
+            else if (kmax + 1 <= 8) LAUNCH_E(k2_estep, 8, 64);
+            else if (kmax + 1 <= 12) LAUNCH_E(k2_estep, 12, 64);
+            else if (kmax + 1 <= 16) LAUNCH_E(k2_estep, 16, 64);
+            else if (kmax + 1 <= 24) LAUNCH_E(k2_estep, 24, 64);
+            else LAUNCH_E(k2_estep, 32, 64);
 #undef LAUNCH_E
             HIPCHK(hipGetLastError());
             if (fine && ev_end(c, 4)) return 1;

@@ -581,10 +581,12 @@ def test_headline_shape_every_utr_vs_cpu_port(oracle):
 
 
 def test_small_call_shapes_give_identical_bits(hip_ctx):
-    """Calls with few live tensor tiles run the M-step in its low-latency shape (the jobs of a tile cut into passes
-    of 16 for separate workgroups, tiles dealt over all XCDs); large calls run one workgroup per tile and 64 jobs.
-    The same jobs through both must agree bit for bit (a UTR's result must not depend on what else shares the
-    launch) - K <= 3 (the 4-column E-step kernel), K = 1..10 (12-column kernel, every exact variant), K = 12..14."""
+    """Calls with few jobs / few live tensor tiles run low-latency kernel shapes: the E-step with 4 wavefronts per job
+    that split the components of a bin (k2_estep_cs), the M-step with a tile's jobs cut into passes of 16 for separate
+    workgroups and the tiles dealt over all XCDs; large calls run one wavefront per job, one workgroup per tile and 64
+    jobs.  The same jobs through every combination must agree bit for bit (a UTR's result must not depend on what else
+    shares the launch) - K <= 3 (the 4-column E-step kernel), K = 1..10 (12-column kernel, every exact variant),
+    K = 12..14 (16-column kernel)."""
     from scape_amd.engine import Engine, HipBatch
     from scape_amd.host import prepare_utr
     from scape_amd.synth import synth_utr
@@ -596,21 +598,23 @@ def test_small_call_shapes_give_identical_bits(hip_ctx):
         batch.build()
         plan = Engine.plan(preps, [11 + i for i in range(n_utr)])
         outs = {}
-        for name, split in (("throughput", "0"), ("low_latency", "1000000")):
-            os.environ["SCAPE_HIP_SPLIT_MAXTILES"] = split
+        for name, wide, split in (("throughput", "0", "0"), ("low_latency", "1000000", "1000000"),
+                                  ("wide_estep_only", "1000000", "0"), ("split_mstep_only", "0", "1000000")):
+            os.environ["SCAPE_HIP_WIDE_MAXJOBS"], os.environ["SCAPE_HIP_SPLIT_MAXTILES"] = wide, split
             try:
                 outs[name] = [a.copy() for a in batch.em_packed(plan["main"])]
             finally:
-                del os.environ["SCAPE_HIP_SPLIT_MAXTILES"]
-        ref, got = outs["throughput"], outs["low_latency"]
+                del os.environ["SCAPE_HIP_WIDE_MAXJOBS"], os.environ["SCAPE_HIP_SPLIT_MAXTILES"]
+        ref = outs.pop("throughput")
         nlb = ref[4]
         assert nlb.min() >= 2
-        for x, y, what in zip(ref, got, ("alpha", "beta", "ws", "bic", "n_lb", "lb")):
-            if what == "lb":
-                mask = np.arange(x.shape[1])[None, :] < nlb[:, None]
-                assert np.array_equal(x[mask], y[mask]), (kcap, what)
-            else:
-                assert np.array_equal(x, y), (kcap, what)
+        for name, got in outs.items():
+            for x, y, what in zip(ref, got, ("alpha", "beta", "ws", "bic", "n_lb", "lb")):
+                if what == "lb":
+                    mask = np.arange(x.shape[1])[None, :] < nlb[:, None]
+                    assert np.array_equal(x[mask], y[mask]), (kcap, name, what)
+                else:
+                    assert np.array_equal(x, y), (kcap, name, what)
         batch.free()
 
 
