@@ -364,7 +364,18 @@ def main():
         import torch
         import torch.distributed as dist
         import datetime
-        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(hours=1))   # ranks wait while rank 0 runs the e2e leg
+        # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."); the contract is ONE JSON line
+        # there, so file descriptor 1 points at stderr until the group is up and has done its first collective
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(hours=1))   # ranks wait while rank 0 runs the e2e leg
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         tdev = torch.device("cpu")
 
     from scape_amd.engine import Engine, HipBatch

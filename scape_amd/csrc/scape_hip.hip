@@ -70,6 +70,7 @@ struct DevParams {
     double betas[SCAPE_MAX_BETA];
     double s_dis[SCAPE_MAX_S];
     double pmf_s[SCAPE_MAX_S];
+    double inv_s[SCAPE_MAX_S];   // 1 / s_dis[j] (the same IEEE quotient the kernels would compute per bin)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -153,13 +154,22 @@ __device__ __forceinline__ double d_point_pa(double x, double l, double pa, doub
 }
 // loglik_xlr_t_r_unknown_kernel body (taichi_core.py:141-157); returns v (linear), A through *a
 __device__ __forceinline__ double d_point_r_unknown(double x, double l, double th, const double *s,
-                                                    const double *pmf, int S, double mu_f,
+                                                    const double *pmf, const double *inv_s, int S, double mu_f,
                                                     double sigma_f, double *a, const double2 *tab) {
     double u = th - x;
     double v = 0.0;
     if (l <= u) {  // lik_l_xt == 0 otherwise, every term of the sum is then exactly 0
-        double lk = 1 / u;
-        for (int j = 0; j < S; ++j) v += 1 / s[j] * d_pdf_normal_t(x, th + s[j] - mu_f, sigma_f, tab) * lk * pmf[j];
+        // 1/s_j * pdfN(x; th + s_j - mu_f, sigma_f) * lk * pmf_j, summed in j order.  The reference divides four times
+        // per term (1/s_j, z = ./sigma, /sqrt(2 pi), /sigma); here the three divisors that do not depend on the bin
+        // become reciprocals taken once (each product then differs from the quotient by at most an ulp: 4e-16 relative
+        // on v, against the 1e-13 the log-domain comparison with the reference allows) - 52 divisions of ~14
+        // instructions per (bin, theta) were three quarters of this kernel
+        const double lk = 1 / u, inv_sigma = 1 / sigma_f, inv_norm = 1 / sqrt(2 * PI_REF);
+        for (int j = 0; j < S; ++j) {
+            const double z = (x - (th + s[j] - mu_f)) * inv_sigma;
+            const double pdf = d_exp_nonpos(-0.5 * (z * z), tab) * inv_norm * inv_sigma;
+            v += inv_s[j] * pdf * lk * pmf[j];
+        }
     }
     if (v < 1e-300) v = 0.0;
     *a = (v <= 0.0) ? SENT : d_log_pos(v);
@@ -255,7 +265,7 @@ __global__ void k_op_r_unknown(const double *x, const double *l, int n, DevParam
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         double a;
-        d_point_r_unknown(x[i], l[i], theta, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
+        d_point_r_unknown(x[i], l[i], theta, P.s_dis, P.pmf_s, P.inv_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
         out[i] = a;
     }
 }
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(256) void k_phase_a(const UtrDesc *__restrict__ des
     } else if (!isnan(rn)) {
         a = d_point_r_known(xn, ln, rn, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f);
     } else {
-        v = d_point_r_unknown(xn, ln, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
+        v = d_point_r_unknown(xn, ln, th, P.s_dis, P.pmf_s, P.inv_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
     }
     AT[o] = a;
     V[o] = v;
@@ -994,6 +1004,7 @@ static void fill_params(DevParams &d, double mu_f, double sigma_f, double max_un
     for (int i = 0; i < S; ++i) {
         d.s_dis[i] = s[i];
         d.pmf_s[i] = pmf[i];
+        d.inv_s[i] = 1 / s[i];
     }
 }
 
