@@ -131,6 +131,15 @@ __device__ __forceinline__ double d_exp_nonpos(double x, const double2 *tab) {
     return ldexp(t.x + __builtin_fma(t.x, p, t.y), ni >> 7);
 }
 
+// 1/x for x in [2^-20, 2^20] (no scaling or special cases needed): v_rcp_f64 + two Newton steps, within an ulp of the quotient
+__device__ __forceinline__ double d_rcp_mid(double x) {
+#pragma clang fp contract(off)
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ double d_logw(double w) { return (w <= 0.0) ? SENT : log(w); }
 __device__ __forceinline__ double d_logpdf_normal(double x, double mu, double sigma) {
     double z = (x - mu) / sigma;

@@ -1,5 +1,6 @@
 """End-to-end rate of the exact reference-stream mode over chunk files (the bench's `reference_streams` leg alone),
-with one and with two engines per group of streams.  GPU box: python tools/streams_e2e.py [n_files]"""
+four times in a row: the leg is noisy (12.6 s and 16.5 s alternate on one box for the same 16,384 UTRs).
+GPU box: python tools/streams_e2e.py [n_files]"""
 import os
 import shutil
 import sys
@@ -19,11 +20,10 @@ if __name__ == "__main__":
         tasks = [(os.path.join(root, "pkl_input", f"s.128.{i}.input.pkl"), 10 ** 6 + 128 * i, 128, 2000, 10, 20250225)
                  for i in range(n_files)]
         files = list(pool.ex.map(synth_chunk_file, tasks))
-        for engines in ("1", "2", "1", "2"):
-            os.environ["SCAPE_STREAM_ENGINES"] = engines
+        for rep in range(4):
             t0 = time.perf_counter()
             infer_files(files, root, rng_mode="reference", seed=1, re_run_mode=True, n_max_apa=10, n_min_apa=1)
             dt = time.perf_counter() - t0
-            print(f"{engines} engine(s): {n_files * 128 / dt:.0f} UTRs/s ({dt:.2f} s)", flush=True)
+            print(f"run {rep}: {n_files * 128 / dt:.0f} UTRs/s ({dt:.2f} s)", flush=True)
     finally:
         shutil.rmtree(root, ignore_errors=True)
