@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "scape_hip.h"
@@ -885,7 +886,9 @@ struct DevBuf {
         if (bytes <= cap && p) return 0;
         // a buffer that has to grow gets 1/8 headroom: successive batches of a stream differ by a few per cent in
         // size, and re-allocating tens of GB for each of them costs more than the batch itself
-        const bool regrow = p != nullptr;
+        // (large buffers get it from the start: device memory costs ~25 ms per GB to allocate, and the second batch of a
+        // stream is a few per cent larger than the first as often as not)
+        const bool regrow = p != nullptr || bytes > ((size_t)1 << 30);
         if (p) {
             (void)hipFree(p);
             p = nullptr;
@@ -1545,11 +1548,14 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
     c->m_total = m_total;
     c->tiles_total = tiles_total;
     c->tiles_max_all = tiles_max_all;
+    const bool trace_load = getenv("SCAPE_HIP_DEBUG") != nullptr;
+    const auto t_alloc0 = std::chrono::steady_clock::now();
     if (c->d_x.ensure(nb * 8) || c->d_l.ensure(nb * 8) || c->d_r.ensure(nb * 8) || c->d_pa.ensure(nb * 8) ||
         c->d_cnt.ensure(nb * 8) || c->d_theta.ensure(nt * 8) || c->d_desc.ensure(n_utr * sizeof(UtrDesc)) ||
         c->d_loglist.ensure(loglist.size() * 4) || c->d_AT.ensure(at_total * 8) || c->d_V.ensure(at_total * 8) ||
         c->d_M.ensure(m_total * 8) || c->d_tile_nend.ensure(tiles_total * 4))
         return 1;
+    const auto t_up0 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(c->d_x.p, x, nb * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_l.p, l, nb * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_r.p, r, nb * 8, hipMemcpyHostToDevice, c->stream));
@@ -1560,6 +1566,12 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
     if (!loglist.empty())
         HIPCHK(hipMemcpyAsync(c->d_loglist.p, loglist.data(), loglist.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (trace_load) {
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "scape_hip_batch_load: %d UTRs, tensors %.2f GB, device buffers (re)allocated in %.1f ms, uploads %.1f ms\n", n_utr,
+                (double)(m_total + 2 * at_total) * 8e-9, std::chrono::duration<double, std::milli>(t_up0 - t_alloc0).count(),
+                std::chrono::duration<double, std::milli>(t1 - t_up0).count());
+    }
     c->loaded = true;
     return 0;
 }

@@ -265,8 +265,15 @@ class _Sweep:
         self.done = False
         self.n_jobs = 0
         self.trace = trace
+        self.pred = None        # Engine._predict_outcomes: None / "clean" / ("prune", K') / "stop" - a guess, never a result
 
-    def make_jobs(self):
+    def prune_K(self):
+        """K' of rm_component (:836-839): components of the current best fit that stay."""
+        f = self.best
+        return int(np.count_nonzero(~(f.ws[:f.K] < self.prep.p["min_ws"])))
+
+    def make_jobs(self, predrawn=None):
+        """predrawn = (init_ws table, k_arr) of the prune re-fit when they were drawn ahead (Engine._drive_streams)."""
         q = self.prep
         jobs = []
         if self.stage == "sweep":                       # run(): K = n_max .. n_min (:965)
@@ -280,16 +287,21 @@ class _Sweep:
             Kp = len(keep)
             if Kp == 0:
                 _no_component_left(q)
-            w = self.sampler.init_ws(Kp, q.p["max_unif_ws"])
-            ka = self.sampler.k_arr(Kp)
+            if predrawn is not None:
+                w, ka = predrawn
+            else:
+                w = self.sampler.init_ws(Kp, q.p["max_unif_ws"])
+                ka = self.sampler.k_arr(Kp)
             jobs.append(_Job(self.u, Kp, True, f.a_idx[keep].astype(np.int32), f.b_idx[keep].astype(np.int32), w, ka))
         self.n_jobs += len(jobs)
         return jobs
 
-    def make_packed(self, tables=None):
+    def make_packed(self, tables=None, predrawn=None):
         """make_jobs as padded tables (one native call per sweep, engine._drive's fast path); `tables` = the
         sweep tables when they were drawn together with other streams' (make_packed_many)."""
         q = self.prep
+        if predrawn is not None:
+            return pack_jobs(self.make_jobs(predrawn))
         if self.stage == "sweep" and hasattr(self.sampler, "sweep"):
             jk, a, b, w, ka = tables if tables is not None else self.sampler.sweep(q, self.n_max, self.n_min)
             n = len(jk)
@@ -445,8 +457,14 @@ class Engine:
                     sweeps.append(_Sweep(u, preps[gi], smp, re_run_mode, self.traces[gi] if keep_trace else None))
                 if rng_mode == "reference":
                     deferred = []
-                    for sw in sweeps:
-                        self._drive(batch, [sw], deferred)
+                    if keep_trace:
+                        for sw in sweeps:
+                            self._drive(batch, [sw], deferred)
+                    else:
+                        depth = self._stream_depth(1)
+                        if depth > 1:
+                            self._predict_outcomes(batch, wp, sweeps, re_run_mode)
+                        self._drive_streams(batch, [(shared, sweeps)], deferred, depth=depth)
                     self._finish_deferred(batch, deferred)
                 else:
                     self._drive(batch, sweeps)
@@ -487,7 +505,10 @@ class Engine:
                     took = True
             if not took:
                 break
-        budget = self._budget()
+        # a wave only has to hold a few UTRs of every stream (one per stream is active at a time); device buffers cost
+        # ~25 ms per GB to allocate, so filling the HBM with one wave would add seconds to a job of a few thousand UTRs
+        full = self._budget()
+        budget = min(full, Engine.stream_wave_bytes)
         pos = 0
         while pos < len(order):
             wave, used = [], 0
@@ -495,7 +516,7 @@ class Engine:
                 b = self.utr_bytes(flat[order[pos]])
                 if wave and used + b > budget:
                     break
-                if b > budget:
+                if b > full:
                     raise _lib.ScapeHipError("a UTR's marginal tensor exceeds device memory")
                 wave.append(order[pos])
                 used += b
@@ -503,26 +524,16 @@ class Engine:
             wave.sort()                              # keep each stream's UTRs in file order inside the wave
             batch = HipBatch(self.ctx, [flat[g] for g in wave])
             batch.build()
-            queues = {}
+            queues, wave_sweeps = {}, []
             for u, g in enumerate(wave):
-                queues.setdefault(owner[g], []).append(_Sweep(u, flat[g], samplers[owner[g]], re_run_mode))
+                wave_sweeps.append(_Sweep(u, flat[g], samplers[owner[g]], re_run_mode))
+                queues.setdefault(owner[g], []).append(wave_sweeps[-1])
             done_sweeps, deferred = [], []
-            while queues:
-                heads = [q[0] for q in queues.values()]
-                packs = _Sweep.make_packed_many(heads)
-                pj = concat_packed(packs)
-                out = batch.em_packed(pj)
-                lo = 0
-                for sw, pk in zip(heads, packs):
-                    sw.absorb_packed(pj, out, lo, lo + len(pk))
-                    lo += len(pk)
-                self._defer_prunes(heads, deferred)             # re-fits wait for the end of the wave
-                waiting = {id(sw) for sw, _pk in deferred}
-                for si in list(queues):
-                    if queues[si][0].done or id(queues[si][0]) in waiting:
-                        done_sweeps.append(queues[si].pop(0))
-                        if not queues[si]:
-                            del queues[si]
+            depth = self._stream_depth(len(queues))
+            if depth > 1:
+                self._predict_outcomes(batch, [flat[g] for g in wave], wave_sweeps, re_run_mode)
+            self._drive_streams(batch, [(samplers[si], q) for si, q in queues.items()], deferred, done_sweeps.append,
+                                depth=depth)
             self._finish_deferred(batch, deferred)
             labs = batch.labels([(sw.u, sw.best) for sw in done_sweeps])
             for sw in done_sweeps:
@@ -628,7 +639,7 @@ class Engine:
         return dict(main=pj, spans=spans, states=states, prune_w=prune_w, prune_ka=prune_ka,
                     prune_states=prune_states)
 
-    def process(self, batch, preps, plan, re_run_mode=True):
+    def process(self, batch, preps, plan, re_run_mode=True, build=True, labels=True):
         """One pass of the hot path over a resident batch: Phase A/B, the main EM sweep, BIC model
         selection, prune re-fits, re-run sweeps and labels.  Returns [(Fit, labels_bin, n_jobs)]."""
         from time import perf_counter as _now
@@ -637,7 +648,8 @@ class Engine:
         # engines that share a device take turns for the long kernels (two EM sweeps at once only slow each
         # other down); uploads, host-side selection and the short re-fit launches overlap freely
         ms0 = batch.timing(2)[0]          # (synchronises: read before the build is queued, not between build and EM)
-        batch.build()            # queued, not awaited: the EM call's host-side table checks run while the GPU builds
+        if build:
+            batch.build()        # queued, not awaited: the EM call's host-side table checks run while the GPU builds
         with (self.sweep_lock if self.sweep_lock is not None else contextlib.nullcontext()):
             out = batch.em_packed(pj, reuse_buffers=True)
             self.last_main_em_ms = batch.timing(2)[0] - ms0          # HIP-event time of the sweep launch
@@ -716,6 +728,9 @@ class Engine:
         for u, (rpj, rout, i) in refit.items():
             fits[u] = batch.fit_at(rpj, rout, i)
         t2 = _now()
+        if not labels:
+            return [(fits[u] if fits[u] is not None else batch.fit_at(pj, out, int(win[u])), None, int(njob_out[u]))
+                    for u in range(U)]
         # ---- labels for every UTR (get_label, :873-881) -------------------------------------------
         kmax_f = max(1, int(Kw.max()), max((f.K for f in fits if f is not None), default=1))
         la = np.zeros((U, kmax_f), dtype=np.int32)
@@ -770,6 +785,155 @@ class Engine:
             sw.absorb_packed(pj, out, lo, lo + len(pk))
             lo += len(pk)
         deferred.clear()
+
+    # ---- the exact-stream modes: UTRs of one random stream, several per EM call --------------------------
+    stream_wave_bytes = 32 << 30     # run_streams: tensor bytes of one wave (~850 UTRs of the headline shape)
+    spec_depth = 8        # UTRs of ONE stream that share an EM call (the head + its followers); 1 = strictly serial
+    spec_max_streams = 8  # more streams in flight than this fill the launches with their heads alone (measured: followers
+                          # gain 1.5x at 2 streams, 1.2x at 8, lose 10-25 % at 16-32 - the prediction pass is a second fit)
+    spec_seed = 0x5CA9E     # seeds of the outcome-prediction pass (any value: predictions steer speed, never results)
+    spec_stats = dict(calls=0, utrs_kept=0, utrs_discarded=0, predicted=0, predicted_right=0)
+
+    def _stream_depth(self, n_streams):
+        return max(1, Engine.spec_depth) if n_streams <= Engine.spec_max_streams else 1
+
+    def _predict_outcomes(self, batch, preps, sweeps, re_run_mode):
+        """Guess how each UTR of the wave will leave its random stream - clean, pruned to K' components, or re-run -
+        by fitting the whole wave once in the batched per-UTR-seed mode (one resident-batch pass, ~0.4 ms per UTR at
+        the headline shape).  The guess only decides which tables the followers of a UTR are drawn from ahead of time
+        (_drive_streams); a wrong guess costs a discarded follower, never a different result."""
+        if len(preps) < 2 or any(q.fixed_run for q in preps):
+            return                                    # fixed_run ends clean by construction (:1009-1017)
+        plan = self.plan(preps, [(Engine.spec_seed + 7919 * i) % (2 ** 32) for i in range(len(preps))])
+        out = self.process(batch, preps, plan, re_run_mode=False, build=False, labels=False)
+        for sw, (fit, _lab, nj) in zip(sweeps, out):
+            n_sweep = (sw.n_max - sw.n_min + 1) * N_TRIAL
+            if re_run_mode and fit.K == sw.n_max:
+                sw.pred = "stop"                      # a re-run is likely: nothing is drawn ahead past this UTR
+            elif nj > n_sweep:
+                sw.pred = ("prune", fit.K)
+            else:
+                sw.pred = "clean"
+
+    @staticmethod
+    def _drive_streams(batch, streams, deferred, on_done=None, depth=1):
+        """streams: [(FastSampler, sweeps of that stream in file order)].  Runs every stream to its end, up to `depth`
+        UTRs of a stream per EM call.
+
+        UTR i+1's restarts are drawn from wherever UTR i left the generator (apa_core.py:125, :1119-1130), and that
+        depends on UTR i's OUTCOME through two events only: a prune (rm_component draws init_ws + gen_k_arr for the
+        K' components that stay, :843 -> :709 -> :720) and a re-run (subsample_run sweeps again, :1023-1030).  Given
+        the outcome class - clean, or pruned to K' - the generator's state after UTR i is known before any EM runs.
+        So the followers of a UTR are drawn from the state its PREDICTED outcome class leaves (sw.pred; the prune
+        tables of that K' are drawn in stream order, ahead of their use) and ride in the same EM call.  After the call
+        the results are taken in stream order exactly as far as every prediction held; from the first wrong one on,
+        the generator goes back to the state saved after that UTR's own sweep draws, the UTR is finished the serial
+        way and its followers are drawn again.  Every job therefore runs from the tables the serial loop gives it,
+        and a job's bits do not depend on what else shares the call (tests: small-call shapes), so results, job counts
+        and the generator's final state are those of the serial loop (depth 1).
+        """
+        active = [[smp, list(sws), 0] for smp, sws in streams if len(sws)]
+        if len(active) < Engine.pingpong_min_streams:
+            while active:
+                prepared = Engine._streams_prepare(active, depth)
+                active = Engine._streams_absorb(active, prepared, batch.em_packed(prepared[0]), deferred, on_done)
+            return
+        # many streams: two alternating halves - while the GPU runs the EM call of one half (a worker thread inside the
+        # library call, GIL released), this thread takes in the other half's results and draws its next tables.  Calls
+        # on the handle stay strictly one after another; which streams share a call never changes a result.
+        from concurrent.futures import ThreadPoolExecutor
+        halves = [active[0::2], active[1::2]]
+        with ThreadPoolExecutor(1) as gpu:
+            prepared = [Engine._streams_prepare(h, depth) for h in halves]
+            futs = [gpu.submit(batch.em_packed, pr[0]) for pr in prepared]
+            h = 0
+            while halves[0] or halves[1]:
+                if halves[h]:
+                    out = futs[h].result()
+                    halves[h] = Engine._streams_absorb(halves[h], prepared[h], out, deferred, on_done)
+                    if halves[h]:
+                        prepared[h] = Engine._streams_prepare(halves[h], depth)
+                        futs[h] = gpu.submit(batch.em_packed, prepared[h][0])
+                h ^= 1
+
+    pingpong_min_streams = 32    # fewer streams than this: one call at a time (a half would leave the GPU under-filled)
+
+    @staticmethod
+    def _streams_prepare(active, depth):
+        """Draw the tables of the next EM call: up to `depth` UTRs of every active stream (see _drive_streams)."""
+        chains = [st[1][st[2]:st[2] + depth] for st in active]
+        packs = [[] for _ in active]
+        marks = [[] for _ in active]      # generator state after each sweep's own draws
+        ahead = [[] for _ in active]      # prune tables drawn ahead: (K', init_ws, k_arr) or None
+        for pos in range(depth):          # position by position: the streams' sweeps of one position share a threaded call
+            col = [(si, ch[pos]) for si, ch in enumerate(chains) if pos < len(ch)]
+            if not col:
+                break
+            for (si, sw), pk in zip(col, _Sweep.make_packed_many([sw for _si, sw in col])):
+                smp = active[si][0]
+                packs[si].append(pk)
+                marks[si].append(smp.state.copy() if depth > 1 else None)
+                pre = None
+                if pos + 1 < len(chains[si]):
+                    pred = sw.pred if sw.best is None else "stop"      # a re-run's sweep has no prediction of its own
+                    if pred == "stop":
+                        chains[si] = chains[si][:pos + 1]
+                    elif isinstance(pred, tuple):
+                        Kp = pred[1]
+                        pre = (Kp, smp.init_ws(Kp, sw.prep.p["max_unif_ws"]), smp.k_arr(Kp))
+                ahead[si].append(pre)
+        return concat_packed([pk for ps in packs for pk in ps]), chains, packs, marks, ahead
+
+    @staticmethod
+    def _streams_absorb(active, prepared, out, deferred, on_done):
+        """Take the results of one EM call in stream order, as far as the predictions held; returns the streams that
+        still have UTRs."""
+        pj, chains, packs, marks, ahead = prepared
+        stats = Engine.spec_stats
+        stats["calls"] += 1
+        lo, nxt = 0, []
+        for st, ch, ps, mk, ah in zip(active, chains, packs, marks, ahead):
+            smp, live = st[0], True
+            for j, (sw, pk) in enumerate(zip(ch, ps)):
+                hi = lo + len(pk)
+                if not live:
+                    sw.n_jobs -= len(pk)               # drawn from a state the stream never reached: discarded
+                    stats["utrs_discarded"] += 1
+                    lo = hi
+                    continue
+                sw.absorb_packed(pj, out, lo, hi)
+                lo = hi
+                stats["utrs_kept"] += 1
+                pre = ah[j]
+                last = j + 1 == len(ch)
+                if not last:
+                    stats["predicted"] += 1
+                if sw.done:                            # clean end
+                    if pre is not None:                # ... but the followers were drawn past a prune's draws
+                        smp.state[:] = mk[j]
+                        live = False
+                elif sw.stage == "prune" and sw.trace is None and Engine.defer_prunes:
+                    # the re-fit's tables belong here in the stream; the EM call waits for the wave's other re-fits
+                    if pre is not None and pre[0] == sw.prune_K():
+                        deferred.append((sw, sw.make_packed(predrawn=pre[1:])))
+                    else:
+                        if not last:
+                            smp.state[:] = mk[j]
+                            live = False
+                        deferred.append((sw, sw.make_packed()))
+                else:                                  # a re-run sweep (or a traced prune): stays the head of its stream
+                    if not last:
+                        smp.state[:] = mk[j]
+                        live = False
+                    continue
+                if live and not last:
+                    stats["predicted_right"] += 1
+                st[2] += 1
+                if on_done is not None:
+                    on_done(sw)
+            if st[2] < len(st[1]):
+                nxt.append(st)
+        return nxt
 
     @staticmethod
     def _drive(batch, sweeps, deferred=None):

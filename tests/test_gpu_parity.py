@@ -194,6 +194,92 @@ def test_full_pipeline_reference_stream(name):
         assert np.array_equal(para.cb_id_arr, f[f"u{i}_cb_id"]) and np.array_equal(para.readID_arr, f[f"u{i}_read_id"])
 
 
+@pytest.mark.parametrize("name", TRACES)
+def test_reference_stream_with_followers_vs_reference_trace(name):
+    """The CLI's default path (no call trace kept): the UTRs of the chunk's one random stream ride several per EM call
+    (Engine._drive_streams) - the reference's final Parameters and the generator state it leaves must come out."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    f = load_npz(f"trace_{name}.npz")
+    p = trace_params(f)
+    preps = [prepare_utr(utr_df(f, i)[1], gene_info_str=utr_df(f, i)[0], pre_para=trace_pre_para(f), **p)
+             for i in range(int(f["n_utr"]))]
+    eng = Engine(device=0)
+    before = dict(Engine.spec_stats)
+    res = eng.run(preps, rng_mode="reference", seed=int(f["seed"]), re_run_mode=bool(p["re_run_mode"]))
+    assert Engine.spec_stats["utrs_kept"] - before["utrs_kept"] >= len(preps)
+    for i, r in enumerate(res):
+        para = to_parameters(r)
+        assert para.K == int(f[f"u{i}_res_K"]), (name, i)
+        assert np.array_equal(para.alpha_arr, f[f"u{i}_res_alpha_arr"])
+        assert np.array_equal(para.beta_arr, f[f"u{i}_res_beta_arr"])
+        assert np.allclose(para.ws, f[f"u{i}_res_ws"], rtol=1e-9, atol=1e-13)
+        assert para.bic == pytest.approx(float(f[f"u{i}_res_bic"]), rel=1e-10)
+        assert np.array_equal(para.label_arr, f[f"u{i}_res_label_arr"])
+        assert np.allclose(para.lb_arr, f[f"u{i}_res_lb_arr"], rtol=1e-10)
+
+
+def test_stream_followers_do_not_change_results():
+    """Strictly serial (spec_depth 1) against 3 and 8 UTRs of a stream per EM call, on chunks whose UTRs prune, re-run
+    (n_max_apa 3 with re_run_mode) and end clean: identical fits bit for bit, identical labels, job counts and final
+    generator state; also for two streams in flight (run_streams)."""
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    chunks = []
+    for kcap, reads, n_utr, base in ((3, 400, 14, 7700), (6, 600, 10, 7800)):
+        kw = dict(n_max_apa=kcap, n_min_apa=1)
+        chunks.append([prepare_utr(df, gene_info_str=g, **kw)
+                       for g, df, _ in (synth_utr(i, reads, k_cap=5, base_seed=base) for i in range(n_utr))])
+    eng = Engine(device=0)
+    keep, keep_pp = Engine.spec_depth, Engine.pingpong_min_streams
+    got = {}
+    try:
+        for depth in (1, 3, 8):
+            Engine.spec_depth = depth
+            before = dict(Engine.spec_stats)
+            runs = []
+            for preps in chunks:
+                rs = np.random.RandomState(5)
+                res = eng.run(preps, rng_mode="reference", rs=rs, re_run_mode=True)
+                runs.append((res, rs.get_state()[1].copy(), rs.get_state()[2]))
+            streams = eng.run_streams([(preps, 9) for preps in chunks], re_run_mode=True)
+            got[depth] = (runs, streams, {k: Engine.spec_stats[k] - before[k] for k in before})
+        # the two-halves schedule of many streams (a worker thread runs the EM call of one half while the other half's
+        # results are taken in), forced onto these two streams
+        Engine.spec_depth, Engine.pingpong_min_streams = 3, 2
+        halves = eng.run_streams([(preps, 9) for preps in chunks], re_run_mode=True)
+    finally:
+        Engine.spec_depth, Engine.pingpong_min_streams = keep, keep_pp
+    assert got[1][2]["utrs_discarded"] == 0 and got[1][2]["predicted"] == 0
+    # some predictions held (fewer calls than UTRs + re-runs), some did not (followers drawn again)
+    assert got[8][2]["utrs_discarded"] > 0 and got[8][2]["calls"] < got[1][2]["calls"]
+    assert 0 < got[8][2]["predicted_right"] < got[8][2]["predicted"]
+
+    def same(r1, r2):
+        assert r1.n_jobs == r2.n_jobs
+        a, b = r1.fit, r2.fit
+        assert a.K == b.K and a.bic == b.bic
+        for x, y in ((a.a_idx, b.a_idx), (a.b_idx, b.b_idx), (a.ws, b.ws), (a.lb, b.lb), (r1.labels_bin, r2.labels_bin)):
+            assert np.array_equal(x, y)
+
+    ks = set()
+    for depth in (3, 8):
+        for (res1, key1, pos1), (resd, keyd, posd) in zip(got[1][0], got[depth][0]):
+            assert np.array_equal(key1, keyd) and pos1 == posd
+            for r1, r2 in zip(res1, resd):
+                same(r1, r2)
+                ks.add((r1.fit.K, r1.n_jobs))
+        for s1, sd in zip(got[1][1], got[depth][1]):
+            for r1, r2 in zip(s1, sd):
+                same(r1, r2)
+    for s1, sd in zip(got[1][1], halves):
+        for r1, r2 in zip(s1, sd):
+            same(r1, r2)
+    assert len({nj for _k, nj in ks}) >= 3      # clean ends, prunes (+1 job) and re-runs (another sweep) are all present
+
+
 # ---------------------------------------------------------------- CLI end to end vs the committed example outputs
 # (fixture, UTR) -> (ws abs tolerance, bic rel tolerance) where the reference at its current code reproduces the
 # committed K / alpha / beta / labels exactly (measured: tests/golden/trace_*.npz res_* vs fixture_*.npz gold_*);
