@@ -339,6 +339,8 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
                                                  int *__restrict__ err_flag, int n_utr, int T_max,
                                                  int32_t *__restrict__ tile_nend, int probe) {
     extern __shared__ double sm[];
+    __shared__ double2 s_exptab[128];
+    d_load_exptab(s_exptab, threadIdx.x, 256);
     // blocks b and b+8 share an XCD: all grid points of a UTR go to one XCD so its V rows (each is
     // read by ~43 neighbouring alphas) are fetched into one L2 only.  Placement only affects speed.
     const int id = blockIdx.x, slot = id >> 3;
@@ -438,16 +440,17 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
         const double *Vu = V + (size_t)d.at_off;
         const int lane = tid & 63, wave = tid >> 6, kq = lane >> 4, rc = lane & 15;
         const int nblocks = d.Np >> 4;
-        for (int nb = wave; nb < nblocks; nb += 4) {
-            const int n = nb * 16 + rc;
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-            for (int w0 = 0; w0 < Wall; w0 += 4) {
-                const int wr = min(lo_all + w0 + kq, d.T - 1);     // past the window the weight is 0
-                const double bv = Vu[(size_t)wr * d.Np + n];
-                const double av = pm[rc * WP + w0 + kq];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
+        // Tap steps whose four rows all exist (lo_all + w0 + 3 <= T - 1) run without a row clamp: the loop body is one
+        // pointer add, one load, one LDS read and the MFMA per block of bins; the (at most one) step that reaches past
+        // the last grid point clamps its row - its weight is 0 there.  Two blocks of 16 bins share every weight fragment.
+        const int steps = (probe & 32) ? 1 : (Wall + 3) >> 2;
+        const int full = max(0, min(steps, (d.T - lo_all) >> 2));
+        const size_t rstep = (probe & 64) ? 0 : (size_t)4 * d.Np;
+        const double *pw = pm + rc * WP + kq;
+        const double *vbase = Vu + (size_t)(lo_all + kq) * d.Np + rc;
+        const bool is_u = true;
+        (void)is_u;
+        auto finish = [&](int n, const v4d &acc) {
             if (n >= d.N) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -456,11 +459,50 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (kq + 4 * q < B) {
-                        const double val = (acc[q] > 0.0) ? d_log_pos(acc[q]) : SENT;
-                        Mi[(size_t)(kq + 4 * q) * d.Np + n] = val;
+                        const double val = (probe & 8) ? acc[q] : ((acc[q] > 0.0) ? d_log_pos(acc[q]) : SENT);
+                        if (!(probe & 16)) Mi[(size_t)(kq + 4 * q) * d.Np + n] = val;
+                        else if (val == 1.2345) Mi[0] = val;
                         note(kq + 4 * q, n, val);
                     }
             }
+        };
+        int nb = wave;
+        for (; nb + 4 < nblocks; nb += 8) {
+            const double *v0 = vbase + nb * 16, *v1 = v0 + 64;
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            int st = 0;
+#pragma unroll 4
+            for (; st < full; ++st) {
+                const double av = pw[4 * st];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, *v0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, *v1, acc1, 0, 0, 0);
+                v0 += rstep;
+                v1 += rstep;
+            }
+            for (; st < steps; ++st) {
+                const int wr = min(lo_all + 4 * st + kq, d.T - 1);
+                const double av = pw[4 * st];
+                const double *vr = Vu + (size_t)wr * d.Np + nb * 16 + rc;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, vr[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, vr[64], acc1, 0, 0, 0);
+            }
+            finish(nb * 16 + rc, acc0);
+            finish(nb * 16 + 64 + rc, acc1);
+        }
+        for (; nb < nblocks; nb += 4) {
+            const double *v0 = vbase + nb * 16;
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0};
+            int st = 0;
+#pragma unroll 4
+            for (; st < full; ++st) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pw[4 * st], *v0, acc0, 0, 0, 0);
+                v0 += rstep;
+            }
+            for (; st < steps; ++st) {
+                const int wr = min(lo_all + 4 * st + kq, d.T - 1);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pw[4 * st], Vu[(size_t)wr * d.Np + nb * 16 + rc], acc0, 0, 0, 0);
+            }
+            finish(nb * 16 + rc, acc0);
         }
     } else if (!all_log) {
         const double *Vu = V + (size_t)d.at_off;
@@ -517,7 +559,8 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
             if (t > mx) mx = t;
         }
         double sum = 0.0;
-        for (int w = 0; w < W; ++w) sum += exp(Au[(size_t)(a + w) * d.Np + n] + gj[w] - Gj - mx);
+        // every argument is <= 0 (mx is the maximum): the table exp of the E-step, 18 instructions instead of ~40
+        for (int w = 0; w < W; ++w) sum += d_exp_nonpos(Au[(size_t)(a + w) * d.Np + n] + gj[w] - Gj - mx, s_exptab);
         const double val = d_log_pos(sum) + mx;
         Mi[(size_t)j * d.Np + n] = val;
         note(j, n, val);
