@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <chrono>
 #include <vector>
 
@@ -443,41 +444,72 @@ __global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ des
         // Tap steps whose four rows all exist (lo_all + w0 + 3 <= T - 1) run without a row clamp: the loop body is one
         // pointer add, one load, one LDS read and the MFMA per block of bins; the (at most one) step that reaches past
         // the last grid point clamps its row - its weight is 0 there.  Two blocks of 16 bins share every weight fragment.
-        const int steps = (probe & 32) ? 1 : (Wall + 3) >> 2;
+        const int steps = (Wall + 3) >> 2;
         const int full = max(0, min(steps, (d.T - lo_all) >> 2));
-        const size_t rstep = (probe & 64) ? 0 : (size_t)4 * d.Np;
+        const size_t rstep = (size_t)4 * d.Np;
         const double *pw = pm + rc * WP + kq;
         const double *vbase = Vu + (size_t)(lo_all + kq) * d.Np + rc;
-        const bool is_u = true;
-        (void)is_u;
+        // The 16 x 16 result block: row kq + 4q of lane (kq, rc) is beta kq + 4q of bin n.  Written without divergent
+        // branches (the logs are taken on every lane, the stores and the extent bookkeeping are predicated): the
+        // per-value `if`s of a straightforward version compiled to ~40 exec-mask sequences per block.
         auto finish = [&](int n, const v4d &acc) {
-            if (n >= d.N) {
+            const bool pad = n >= d.N;
+            const int nn = pad ? d.N - 1 : n;
+            const bool lin = !pad && isnan(pa[d.bin_off + nn]) && isnan(r[d.bin_off + nn]);   // r-unknown bin: this path's
+            const bool wr = pad || lin;
+            bool f0 = false, f1 = false;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (kq + 4 * q < B) Mi[(size_t)(kq + 4 * q) * d.Np + n] = 0.0;
-            } else if (isnan(pa[d.bin_off + n]) && isnan(r[d.bin_off + n])) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (kq + 4 * q < B) {
-                        const double val = (probe & 8) ? acc[q] : ((acc[q] > 0.0) ? d_log_pos(acc[q]) : SENT);
-                        if (!(probe & 16)) Mi[(size_t)(kq + 4 * q) * d.Np + n] = val;
-                        else if (val == 1.2345) Mi[0] = val;
-                        note(kq + 4 * q, n, val);
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const int j = kq + 4 * q;
+                const double a = acc[q];
+                const bool pos = a > 0.0;
+                const double lg = d_log_pos(pos ? a : 1.0);
+                const double val = pad ? 0.0 : (pos ? lg : SENT);
+                if (wr && j < B) Mi[(size_t)j * d.Np + n] = val;
+                const bool fin = lin && pos && j < B;
+                f0 |= fin && j < j_split;
+                f1 |= fin && j >= j_split;
             }
+            fin0 = max(fin0, f0 ? n + 1 : 0);
+            fin1 = max(fin1, f1 ? n + 1 : 0);
         };
         int nb = wave;
         for (; nb + 4 < nblocks; nb += 8) {
             const double *v0 = vbase + nb * 16, *v1 = v0 + 64;
             v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
             int st = 0;
-#pragma unroll 4
-            for (; st < full; ++st) {
-                const double av = pw[4 * st];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, *v0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, *v1, acc1, 0, 0, 0);
-                v0 += rstep;
-                v1 += rstep;
+            // Four tap steps per trip: their eight V fragments are requested together, then consumed - one wait on the
+            // L2 per trip instead of one per step.  (The loop is bound by that latency, not by issue: 8 or 31
+            // instructions per MFMA made no difference, batching the loads took 1.3 ms off; the 1-3 steps left over
+            // are batched the same way: another 0.5 ms.  Measured and not kept: predicated batches of 4 / 6 / 12 steps
+            // (the compiler serialises them), the next pair's first batch requested before this pair's logs and
+            // stores (3 wavefronts per SIMD instead of 4: +1.5 ms; held to 4: -0.15 ms), batched loads in the
+            // log-domain path and the grid points of the window searches in LDS (registers: 3 wavefronts, +2 ms).)
+            auto batch = [&](auto nbc) {
+                constexpr int NB = decltype(nbc)::value;
+                double b0[NB], b1[NB], av[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    b0[k] = v0[k * rstep];
+                    b1[k] = v1[k * rstep];
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) av[k] = pw[4 * (st + k)];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], b0[k], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k], b1[k], acc1, 0, 0, 0);
+                }
+                v0 += NB * rstep;
+                v1 += NB * rstep;
+                st += NB;
+            };
+            while (st + 4 <= full) batch(std::integral_constant<int, 4>());
+            switch (full - st) {
+                case 3: batch(std::integral_constant<int, 3>()); break;
+                case 2: batch(std::integral_constant<int, 2>()); break;
+                case 1: batch(std::integral_constant<int, 1>()); break;
+                default: break;
             }
             for (; st < steps; ++st) {
                 const int wr = min(lo_all + 4 * st + kq, d.T - 1);

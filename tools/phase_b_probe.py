@@ -16,7 +16,7 @@ preps = [prepare_utr(df, gene_info_str=g, n_max_apa=10, n_min_apa=1)
 eng = Engine()
 batch = HipBatch(eng.ctx, preps)
 lib, h = eng.ctx.lib, eng.ctx.h
-for probe in (0, 1, 64, 65, 32, 33, 0):
+for probe in (0, 1, 2, 3, 0):
     os.environ["SCAPE_HIP_PB_PROBE"] = str(probe)
     batch.build()
     lib.scape_hip_timing_reset(h)
