@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_phase_a(const UtrDesc *__restrict__ des
 // LDS layout (f64): g[B][Wmax] | p[B][Wmax] | G[B] | lo[B] hi[B] (int32 pairs)
 // ------------------------------------------------------------------------------------------
 template <int BMAX>
-__global__ __launch_bounds__(256) void k_phase_b(const UtrDesc *__restrict__ descs, DevParams P,
+__global__ __launch_bounds__(256, 5) void k_phase_b(const UtrDesc *__restrict__ descs, DevParams P,
                                                  const double *__restrict__ r,
                                                  const double *__restrict__ pa,
                                                  const double *__restrict__ theta,
