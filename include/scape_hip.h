@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SCAPE_HIP_ABI_VERSION 2
+#define SCAPE_HIP_ABI_VERSION 3
 #define SCAPE_SENT (-3.4028234663852886e38)
 #define SCAPE_MAX_BETA 64    /* max len(predef_beta_arr) */
 #define SCAPE_MAX_S 64       /* max len(s_dis_arr)       */
@@ -119,6 +119,14 @@ int scape_hip_batch_em(scape_hip_ctx *ctx, int32_t n_jobs, int32_t kmax, const i
                        const int32_t *beta_idx, const double *ws, const int8_t *k_arr,
                        int32_t *alpha_idx_out, int32_t *beta_idx_out, double *ws_out,
                        double *bic_out, int32_t *n_lb_out, double *lb_out);
+/*
+ * lb_out of scape_hip_batch_em may be NULL (ABI version 3): the lb_arr rows (nround doubles per job, 20 MB for the
+ * 51,200 jobs of a 512-UTR sweep) then stay on the device, and the caller fetches the rows of the few jobs it keeps -
+ * the BIC winners that become Parameters.lb_arr (apa_core.py:760-766, :972) - with this call.  job_idx are indices
+ * into the job tables of the LAST scape_hip_batch_em call on this handle; lb_out is [n_sel][nround], rows valid up
+ * to that job's n_lb.
+ */
+int scape_hip_batch_em_fetch_lb(scape_hip_ctx *ctx, int32_t n_sel, const int32_t *job_idx, double *lb_out);
 /*
  * get_label (apa_core.py:873-881) for n_sel models: per-bin arg-max of the responsibilities.
  * labels_out is indexed like the batch's bins (bin_off of sel_utr[i]); only the bins of the

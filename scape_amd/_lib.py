@@ -52,6 +52,7 @@ SIGNATURES = {
     "scape_hip_batch_build": (c_i, [P_void]),
     "scape_hip_batch_em": (c_i, [P_void, c_i32, c_i32, P_i32, P_i32, P_i32, P_i32, P_i32, P_d, P_i8,
                                  P_i32, P_i32, P_d, P_d, P_i32, P_d]),
+    "scape_hip_batch_em_fetch_lb": (c_i, [P_void, c_i32, P_i32, P_d]),
     "scape_hip_batch_labels": (c_i, [P_void, c_i32, c_i32, P_i32, P_i32, P_i32, P_i32, P_d, P_i32]),
     "scape_hip_batch_fetch_loglik": (c_i, [P_void, c_i32, P_d]),
     "scape_hip_batch_fetch_tensor": (c_i, [P_void, c_i32, P_d]),
@@ -77,7 +78,7 @@ def load_library():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.scape_hip_abi_version() != 2:
+        if lib.scape_hip_abi_version() != 3:
             raise ScapeHipError("libscape_hip.so ABI version mismatch")
         _lib = lib
     return _lib

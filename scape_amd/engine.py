@@ -145,12 +145,14 @@ class HipBatch:
     def build(self):
         check(self.lib.scape_hip_batch_build(self.ctx.h), "batch_build")
 
-    def em_packed(self, pj, reuse_buffers=False):
+    def em_packed(self, pj, reuse_buffers=False, want_lb=True):
         """Run em_algo for packed job tables; returns (alpha_idx, beta_idx, ws, bic, n_lb, lb) arrays.
         reuse_buffers: hand out the same host arrays on every call of this shape (the caller must be
-        done with the previous result) - saves re-allocating ~0.5 KB per job."""
+        done with the previous result) - saves re-allocating ~0.5 KB per job.
+        want_lb=False: the lb_arr rows stay on the device (lb is None; 400 bytes per job, 20 MB per 512-UTR sweep) and
+        the caller fetches the rows of the jobs it keeps with :meth:`em_fetch_lb`."""
         n, kmax = len(pj), pj.kmax
-        key = (n, kmax)
+        key = (n, kmax, want_lb)
         if reuse_buffers and getattr(self, "_em_buf_key", None) == key:
             ao, bo, wo, bic, nlb, lb = self._em_buf
         else:
@@ -158,21 +160,31 @@ class HipBatch:
             wo = np.empty_like(pj.w)
             bic = np.empty(n)
             nlb = np.empty(n, dtype=np.int32)
-            lb = np.empty((n, N_ROUND))          # rows are valid up to n_lb (the device buffer is zero-filled)
+            lb = np.empty((n, N_ROUND)) if want_lb else None   # rows are valid up to n_lb (the device buffer is zero-filled)
             if reuse_buffers:
                 self._em_buf_key, self._em_buf = key, (ao, bo, wo, bic, nlb, lb)
         check(self.lib.scape_hip_batch_em(self.ctx.h, n, kmax, ptr(pj.ju, P_i32), ptr(pj.jk, P_i32),
                                           ptr(pj.jf, P_i32), ptr(pj.a, P_i32), ptr(pj.b, P_i32), ptr(pj.w),
                                           ptr(pj.ka, P_i8), ptr(ao, P_i32), ptr(bo, P_i32), ptr(wo), ptr(bic),
-                                          ptr(nlb, P_i32), ptr(lb)), "batch_em")
+                                          ptr(nlb, P_i32), ptr(lb) if want_lb else None), "batch_em")
         return ao, bo, wo, bic, nlb, lb
 
+    def em_fetch_lb(self, job_idx):
+        """lb_arr rows [len(job_idx), nround] of jobs of the LAST em_packed call (scape_hip_batch_em_fetch_lb)."""
+        idx = i32(job_idx)
+        out = np.empty((len(idx), N_ROUND))
+        if len(idx):
+            check(self.lib.scape_hip_batch_em_fetch_lb(self.ctx.h, len(idx), ptr(idx, P_i32), ptr(out)), "em_fetch_lb")
+        return out
+
     @staticmethod
-    def fit_at(pj, out, i):
+    def fit_at(pj, out, i, lb_row=None):
+        """lb_row: the job's lb_arr row when `out` was produced with want_lb=False (em_fetch_lb)."""
         ao, bo, wo, bic, nlb, lb = out
         K = int(pj.jk[i])
+        row = lb[i] if lb_row is None else lb_row
         return Fit(K=K, a_idx=ao[i, :K].copy(), b_idx=bo[i, :K].copy(), ws=wo[i, :K + 1].copy(),
-                   bic=float(bic[i]), lb=lb[i, :nlb[i]].copy())
+                   bic=float(bic[i]), lb=row[:nlb[i]].copy())
 
     def em(self, jobs):
         """Run em_algo for a list of _Job; returns a list of Fit in the same order."""
@@ -651,7 +663,7 @@ class Engine:
         if build:
             batch.build()        # queued, not awaited: the EM call's host-side table checks run while the GPU builds
         with (self.sweep_lock if self.sweep_lock is not None else contextlib.nullcontext()):
-            out = batch.em_packed(pj, reuse_buffers=True)
+            out = batch.em_packed(pj, reuse_buffers=True, want_lb=False)   # lb rows of the BIC winners only, below
             self.last_main_em_ms = batch.timing(2)[0] - ms0          # HIP-event time of the sweep launch
         self.last_main_counters = batch.em_counters()
         t1 = _now()
@@ -675,6 +687,7 @@ class Engine:
                 tbu = np.argmin(g, axis=1)
                 kbu = int(np.argmin(g[np.arange(len(tbu)), tbu]))
                 win[u] = lo + kbu * N_TRIAL + int(tbu[kbu])
+        lb_win = batch.em_fetch_lb(win)             # Parameters.lb_arr of every UTR's winner (:972), before any other EM call
         Kw = pj.jk[win].astype(np.int64)
         min_ws = np.array([q.p["min_ws"] for q in preps])
         n_max = np.array([q.p["n_max_apa"] for q in preps])
@@ -716,7 +729,7 @@ class Engine:
                     best = batch.fit_at(rpj, rout, i)
                     rs.set_state(_hostlib.state_to_numpy(plan["prune_states"][u][best.K]))
                 else:
-                    best = batch.fit_at(pj, out, int(win[u]))
+                    best = batch.fit_at(pj, out, int(win[u]), lb_win[u])
                     rs.set_state(_hostlib.state_to_numpy(plan["states"][u]))
                 sw = _Sweep(u, preps[u], FastSampler(rs), re_run_mode)
                 sw.best, sw.n_jobs = best, int(njob_out[u])
@@ -729,7 +742,7 @@ class Engine:
             fits[u] = batch.fit_at(rpj, rout, i)
         t2 = _now()
         if not labels:
-            return [(fits[u] if fits[u] is not None else batch.fit_at(pj, out, int(win[u])), None, int(njob_out[u]))
+            return [(fits[u] if fits[u] is not None else batch.fit_at(pj, out, int(win[u]), lb_win[u]), None, int(njob_out[u]))
                     for u in range(U)]
         # ---- labels for every UTR (get_label, :873-881) -------------------------------------------
         kmax_f = max(1, int(Kw.max()), max((f.K for f in fits if f is not None), default=1))
@@ -751,7 +764,7 @@ class Engine:
         t3 = _now()
         res = []
         for u in range(U):
-            f = fits[u] if fits[u] is not None else batch.fit_at(pj, out, int(win[u]))
+            f = fits[u] if fits[u] is not None else batch.fit_at(pj, out, int(win[u]), lb_win[u])
             res.append((f, flat[batch.bin_off[u]:batch.bin_off[u + 1]], int(njob_out[u])))
         t4 = _now()
         self.last_host_ms = dict(build_em=(t1 - t0) * 1e3, select_prune=(t2 - t1) * 1e3, labels=(t3 - t2) * 1e3,

@@ -450,7 +450,24 @@ def test_c_abi_error_paths(hip_ctx):
     assert batch.em([good])[0].K == 2                       # context still usable after errors
     with pytest.raises(_lib.ScapeHipError):
         _lib.Context(device=99)
+    # lb_arr rows left on the device and fetched for chosen jobs (scape_hip_batch_em_fetch_lb, ABI 3)
+    from scape_amd.engine import pack_jobs
+    jobs = [good, _Job(0, 1, False, np.array([5], np.int32), np.array([2], np.int32), np.array([0.7, 0.3]), np.zeros(50, np.int8)), good]
+    pj = pack_jobs(jobs)
+    full = [a.copy() for a in batch.em_packed(pj)]
+    lean = batch.em_packed(pj, want_lb=False)
+    assert lean[5] is None
+    for x, y in zip(full[:5], lean[:5]):
+        assert np.array_equal(x, y)
+    rows = batch.em_fetch_lb([2, 1])
+    assert np.array_equal(rows[0], full[5][2]) and np.array_equal(rows[1], full[5][1])
+    f0, f1 = HipBatch.fit_at(pj, full, 1), HipBatch.fit_at(pj, lean, 1, rows[1])
+    assert np.array_equal(f0.lb, f1.lb) and len(f0.lb) == full[4][1] >= 2
+    with pytest.raises(_lib.ScapeHipError, match="out of range"):
+        batch.em_fetch_lb([3])
     batch.free()
+    with pytest.raises(_lib.ScapeHipError):
+        batch.em_fetch_lb([0])                              # nothing to fetch from after batch_free
 
 
 def test_handle_rejects_concurrent_calls():
