@@ -188,21 +188,39 @@ def infer_files(files, output_dir, device=None, files_in_flight=128, workers=Non
                      stats=stats)             # two engines share the device (pipeline.run_pipeline)
         return written
     engine = Engine(device=device)
-    # groups of chunk files share launches: a first group of about a quarter of the files (short prep before the
-    # GPU starts), then groups of files_in_flight whose prep hides behind the GPU work of the group before
-    from concurrent.futures import ThreadPoolExecutor
-    first = min(files_in_flight, max(16, len(tasks) // 4))
-    groups = [tasks[:first]] + [tasks[i:i + files_in_flight] for i in range(first, len(tasks), files_in_flight)]
-    pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[0]] if groups else []
+    # every file is a stream of its own; files join the running set of streams as their prep finishes (at wave
+    # boundaries, Engine.run_streams_rolling), at most files_in_flight at a time; results are written by a side thread
+    # as files finish.  Prep tasks are handed to the pool a bounded number ahead of the GPU.
+    from concurrent.futures import FIRST_COMPLETED, ThreadPoolExecutor, wait
+    ahead = files_in_flight + 2 * max(1, getattr(pool, "workers", 8))
+    state = dict(next=0, futs={})                         # task index -> future, submitted and not yet admitted
+
+    def top_up():
+        while state["next"] < len(tasks) and len(state["futs"]) < ahead:
+            state["futs"][state["next"]] = pool.ex.submit(prep_chunk_file, tasks[state["next"]])
+            state["next"] += 1
+
+    def more():
+        return bool(state["futs"]) or state["next"] < len(tasks)
+
+    def take(block, room):
+        top_up()
+        if block and state["futs"] and not any(f.done() for f in state["futs"].values()):
+            wait(list(state["futs"].values()), return_when=FIRST_COMPLETED)
+        got = []
+        for ti in sorted(state["futs"]):
+            if len(got) >= room:
+                break
+            if state["futs"][ti].done():
+                got.append((ti, state["futs"].pop(ti).result(), seed))
+        top_up()
+        return got
+
     with ThreadPoolExecutor(1) as writer:
-        writes = []
-        for gi, group in enumerate(groups):
-            streams = [(fu.result(), seed) for fu in pending]
-            pending = [pool.ex.submit(prep_chunk_file, t) for t in groups[gi + 1]] if gi + 1 < len(groups) else []
-            per_file = engine.run_streams(streams, re_run_mode=re_run)
-            for (f, _kw), results in zip(group, per_file):
-                writes.append(writer.submit(_write_results, output_dir, f, results))
-        written = [w.result() for w in writes]
+        writes = {}
+        engine.run_streams_rolling(take, more, lambda ti, res: writes.__setitem__(
+            ti, writer.submit(_write_results, output_dir, files[ti], res)), re_run_mode=re_run, streams_in_flight=files_in_flight)
+        written = [writes[ti].result() for ti in sorted(writes)]
     return written
 
 

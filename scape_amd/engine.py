@@ -497,65 +497,87 @@ class Engine:
         semantics (its UTRs are processed one after another, draws in the reference's order), but the
         current UTRs of ALL streams share each EM launch - chunk files are independent random streams
         (np.random.seed(1) per file, apa_core.py:125), so results equal running the files one by one."""
-        flat, owner = [], []
-        for si, (preps, _seed) in enumerate(streams):
-            for q in preps:
-                flat.append(q)
-                owner.append(si)
-        results = [UtrResult(prep=q) for q in flat]
-        samplers = [FastSampler(np.random.RandomState(seed)) for _p, seed in streams]
-        # streams advance monotonically, so waves are cut over the flat list in round-robin stream order
-        order = []
-        cursors = [0] * len(streams)
-        starts = np.cumsum([0] + [len(p) for p, _ in streams])
-        while True:
-            took = False
-            for si, (preps, _seed) in enumerate(streams):
-                if cursors[si] < len(preps):
-                    order.append(int(starts[si]) + cursors[si])
-                    cursors[si] += 1
-                    took = True
-            if not took:
-                break
-        # a wave only has to hold a few UTRs of every stream (one per stream is active at a time); device buffers cost
-        # ~25 ms per GB to allocate, so filling the HBM with one wave would add seconds to a job of a few thousand UTRs
+        out = [None] * len(streams)
+        ready = [(si, preps, seed) for si, (preps, seed) in enumerate(streams)]
+
+        def take(block, room):
+            got = ready[:room]
+            del ready[:room]
+            return got
+        self.run_streams_rolling(take, lambda: bool(ready), lambda si, res: out.__setitem__(si, res), re_run_mode,
+                                 streams_in_flight=max(1, len(streams)))
+        return out
+
+    stream_wave_utrs = 16    # UTRs one stream brings into a wave at most: early waves stay short, so files that become ready join soon
+    stream_wave_min = 512    # ... unless the wave would hold fewer UTRs than this in all (few streams: longer pieces of each)
+
+    def run_streams_rolling(self, take, more, on_done, re_run_mode=True, streams_in_flight=128):
+        """run_streams over streams that become available while it runs (chunk files whose prep finishes).
+        take(block, room) -> [(tag, preps, seed)] newly available streams, at most `room`; with block=True it waits for
+        at least one unless none is left.  more() -> False once take() can return nothing any more.
+        on_done(tag, [UtrResult]) is called when a stream's last UTR is finished (not necessarily in admission order).
+        Streams join at wave boundaries; a wave takes the next UTRs of every stream in flight, round-robin, up to
+        `stream_wave_utrs` per stream and `stream_wave_bytes` of tensors in all."""
         full = self._budget()
         budget = min(full, Engine.stream_wave_bytes)
-        pos = 0
-        while pos < len(order):
-            wave, used = [], 0
-            while pos < len(order) and len(wave) < 65535:
-                b = self.utr_bytes(flat[order[pos]])
-                if wave and used + b > budget:
+        active = []       # [tag, preps, sampler, cursor, results]
+        while active or more():
+            room = streams_in_flight - len(active)
+            if room > 0 and more():
+                for tag, preps, seed in take(not active, room):
+                    st = [tag, preps, FastSampler(np.random.RandomState(seed)), 0, [UtrResult(prep=q) for q in preps]]
+                    if len(preps):
+                        active.append(st)
+                    else:
+                        on_done(tag, [])
+            if not active:
+                continue
+            wave, used, stop = [], 0, False           # (stream, index within the stream), stream-major order below
+            per_stream = max(Engine.stream_wave_utrs, -(-Engine.stream_wave_min // len(active)))
+            for turn in range(per_stream):
+                took = False
+                for st in active:
+                    i = st[3]
+                    if i >= len(st[1]) or len(wave) >= 65535:
+                        continue
+                    bts = self.utr_bytes(st[1][i])
+                    if bts > full:
+                        raise _lib.ScapeHipError("a UTR's marginal tensor exceeds device memory")
+                    if wave and used + bts > budget:
+                        stop = True
+                        break
+                    wave.append((st, i))
+                    st[3] = i + 1
+                    used += bts
+                    took = True
+                if stop or not took:
                     break
-                if b > full:
-                    raise _lib.ScapeHipError("a UTR's marginal tensor exceeds device memory")
-                wave.append(order[pos])
-                used += b
-                pos += 1
-            wave.sort()                              # keep each stream's UTRs in file order inside the wave
-            batch = HipBatch(self.ctx, [flat[g] for g in wave])
+            wave.sort(key=lambda e: (id(e[0]), e[1]))     # each stream's UTRs contiguous and in file order
+            preps = [st[1][i] for st, i in wave]
+            batch = HipBatch(self.ctx, preps)
             batch.build()
             queues, wave_sweeps = {}, []
-            for u, g in enumerate(wave):
-                wave_sweeps.append(_Sweep(u, flat[g], samplers[owner[g]], re_run_mode))
-                queues.setdefault(owner[g], []).append(wave_sweeps[-1])
+            for u, (st, _i) in enumerate(wave):
+                wave_sweeps.append(_Sweep(u, preps[u], st[2], re_run_mode))
+                queues.setdefault(id(st), (st, []))[1].append(wave_sweeps[-1])
             done_sweeps, deferred = [], []
             depth = self._stream_depth(len(queues))
             if depth > 1:
-                self._predict_outcomes(batch, [flat[g] for g in wave], wave_sweeps, re_run_mode)
-            self._drive_streams(batch, [(samplers[si], q) for si, q in queues.items()], deferred, done_sweeps.append,
-                                depth=depth)
+                self._predict_outcomes(batch, preps, wave_sweeps, re_run_mode)
+            self._drive_streams(batch, [(st[2], q) for st, q in queues.values()], deferred, done_sweeps.append, depth=depth)
             self._finish_deferred(batch, deferred)
             labs = batch.labels([(sw.u, sw.best) for sw in done_sweeps])
             for sw in done_sweeps:
-                g = wave[sw.u]
-                results[g].fit, results[g].labels_bin, results[g].n_jobs = sw.best, labs[sw.u], sw.n_jobs
-        out, k = [], 0
-        for preps, _seed in streams:
-            out.append(results[k:k + len(preps)])
-            k += len(preps)
-        return out
+                st, i = wave[sw.u]
+                r = st[4][i]
+                r.fit, r.labels_bin, r.n_jobs = sw.best, labs[sw.u], sw.n_jobs
+            still = []
+            for st in active:
+                if st[3] < len(st[1]):
+                    still.append(st)
+                else:
+                    on_done(st[0], st[4])
+            active = still
 
     # ---- fully batched path (per-UTR RNG): pre-drawn job tables + vectorised selection -------------
     @staticmethod
@@ -847,9 +869,16 @@ class Engine:
         """
         active = [[smp, list(sws), 0] for smp, sws in streams if len(sws)]
         if len(active) < Engine.pingpong_min_streams:
+            stats, base, cur = Engine.spec_stats, dict(Engine.spec_stats), depth
             while active:
-                prepared = Engine._streams_prepare(active, depth)
+                prepared = Engine._streams_prepare(active, cur)
                 active = Engine._streams_absorb(active, prepared, batch.em_packed(prepared[0]), deferred, on_done)
+                # followers pay while the predictions hold: with p of them right a chain keeps ~1/(1-p) UTRs, the rest
+                # is discarded work - the depth follows the share seen so far in this run (speed only)
+                n_pred = stats["predicted"] - base["predicted"]
+                if depth > 2 and n_pred >= 8:
+                    p_ok = (stats["predicted_right"] - base["predicted_right"]) / n_pred
+                    cur = depth if p_ok >= 0.75 else (max(2, depth // 2) if p_ok >= 0.5 else 2)
             return
         # many streams: two alternating halves - while the GPU runs the EM call of one half (a worker thread inside the
         # library call, GIL released), this thread takes in the other half's results and draws its next tables.  Calls
