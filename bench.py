@@ -229,7 +229,9 @@ def end_to_end(args, pool, dev):
                     n_max_apa=args.kcap, n_min_apa=1)
         dt3 = time.perf_counter() - t0
         reference_streams = dict(value=n_ref / dt3, utrs=n_ref, seconds=dt3, re_run_mode=True,
-                                 chunk_files_in_flight=min(128, len(ref_files)))
+                                 chunk_files_in_flight=min(256, len(ref_files)),
+                                 note="every file its own random stream (the CLI default); files join the running set of "
+                                      "streams as their prep finishes (Engine.run_streams_rolling)")
         return dict(value=args.e2e_utrs / dt, unit="UTRs/s", utrs=args.e2e_utrs, seconds=dt, prep_workers=pool.workers,
                     from_prebinned_chunks=prebinned, reference_streams=reference_streams,
                     chunk_files=len(files), input_bytes=in_bytes, output_bytes=out_bytes,

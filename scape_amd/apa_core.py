@@ -167,7 +167,7 @@ def _write_results(output_dir, pkl_input_file, results):
     return out
 
 
-def infer_files(files, output_dir, device=None, files_in_flight=128, workers=None, stats=None, **kwargs):
+def infer_files(files, output_dir, device=None, files_in_flight=256, workers=None, stats=None, **kwargs):
     """Several chunk files on one GPU; chunk reading / binning runs in a process pool beside the GPU.
 
     rng_mode 'reference' (default): each file keeps the reference's own random stream (np.random.seed(1)
