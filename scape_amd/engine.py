@@ -827,7 +827,7 @@ class Engine:
     spec_max_streams = 8  # more streams in flight than this fill the launches with their heads alone (measured: followers
                           # gain 1.5x at 2 streams, 1.2x at 8, lose 10-25 % at 16-32 - the prediction pass is a second fit)
     spec_seed = 0x5CA9E     # seeds of the outcome-prediction pass (any value: predictions steer speed, never results)
-    spec_stats = dict(calls=0, utrs_kept=0, utrs_discarded=0, predicted=0, predicted_right=0)
+    spec_stats = dict(calls=0, utrs_kept=0, utrs_discarded=0, predicted=0, predicted_right=0, calls_drawn_ahead=0)
 
     def _stream_depth(self, n_streams):
         return max(1, Engine.spec_depth) if n_streams <= Engine.spec_max_streams else 1
@@ -868,22 +868,53 @@ class Engine:
         and the generator's final state are those of the serial loop (depth 1).
         """
         active = [[smp, list(sws), 0] for smp, sws in streams if len(sws)]
-        if len(active) < Engine.pingpong_min_streams:
+        from concurrent.futures import ThreadPoolExecutor
+        if len(active) < Engine.pingpong_min_streams and (depth <= 1 or not Engine.draw_ahead):
             stats, base, cur = Engine.spec_stats, dict(Engine.spec_stats), depth
             while active:
                 prepared = Engine._streams_prepare(active, cur)
-                active = Engine._streams_absorb(active, prepared, batch.em_packed(prepared[0]), deferred, on_done)
-                # followers pay while the predictions hold: with p of them right a chain keeps ~1/(1-p) UTRs, the rest
-                # is discarded work - the depth follows the share seen so far in this run (speed only)
-                n_pred = stats["predicted"] - base["predicted"]
-                if depth > 2 and n_pred >= 8:
-                    p_ok = (stats["predicted_right"] - base["predicted_right"]) / n_pred
-                    cur = depth if p_ok >= 0.75 else (max(2, depth // 2) if p_ok >= 0.5 else 2)
+                active, _held = Engine._streams_absorb(active, prepared, batch.em_packed(prepared[0]), deferred, on_done)
+                cur = Engine._next_depth(depth, cur, stats, base)
+            return
+        if len(active) < Engine.pingpong_min_streams:
+            # few streams with followers.  While the GPU runs a call (worker thread, GIL released), this thread already
+            # draws the tables of the NEXT call as if every prediction of the running one held - exactly what the serial
+            # loop would draw then; they are thrown away otherwise (the host has nothing else to do meanwhile).
+            stats, base, cur = Engine.spec_stats, dict(Engine.spec_stats), depth
+            with ThreadPoolExecutor(1) as gpu:
+                prepared = Engine._streams_prepare(active, cur)
+                while active:
+                    fut = gpu.submit(batch.em_packed, prepared[0])
+                    end_state = [st[0].state.copy() for st in active]        # where each stream stands if every prediction holds
+                    moved = [len(ch) for ch in prepared[1]]
+                    for st, m in zip(active, moved):
+                        st[2] += m
+                    nxt = [st for st in active if st[2] < len(st[1])]
+                    ahead = Engine._streams_prepare(nxt, cur) if nxt else None
+                    for st, m in zip(active, moved):
+                        st[2] -= m
+                    out = fut.result()
+                    was = list(active)
+                    active, held = Engine._streams_absorb(active, prepared, out, deferred, on_done)
+                    new_cur = Engine._next_depth(depth, cur, stats, base)
+                    if ahead is not None and all(held) and new_cur == cur:
+                        prepared = ahead                   # (all held: `active` is `nxt`, in the same order)
+                        stats["calls_drawn_ahead"] += 1
+                        continue
+                    if ahead is not None:                  # never submitted: the sweeps forget the jobs they were handed,
+                        for ch, ps in zip(ahead[1], ahead[2]):
+                            for sw, pk in zip(ch, ps):
+                                sw.n_jobs -= len(pk)
+                        for st, ok, stt in zip(was, held, end_state):
+                            if ok:                         # and a stream whose predictions held goes back to where its chain ended
+                                st[0].state[:] = stt       # (a stream with a wrong one was put right by _streams_absorb)
+                    cur = new_cur
+                    if active:
+                        prepared = Engine._streams_prepare(active, cur)
             return
         # many streams: two alternating halves - while the GPU runs the EM call of one half (a worker thread inside the
         # library call, GIL released), this thread takes in the other half's results and draws its next tables.  Calls
         # on the handle stay strictly one after another; which streams share a call never changes a result.
-        from concurrent.futures import ThreadPoolExecutor
         halves = [active[0::2], active[1::2]]
         with ThreadPoolExecutor(1) as gpu:
             prepared = [Engine._streams_prepare(h, depth) for h in halves]
@@ -892,17 +923,31 @@ class Engine:
             while halves[0] or halves[1]:
                 if halves[h]:
                     out = futs[h].result()
-                    halves[h] = Engine._streams_absorb(halves[h], prepared[h], out, deferred, on_done)
+                    halves[h], _held = Engine._streams_absorb(halves[h], prepared[h], out, deferred, on_done)
                     if halves[h]:
                         prepared[h] = Engine._streams_prepare(halves[h], depth)
                         futs[h] = gpu.submit(batch.em_packed, prepared[h][0])
                 h ^= 1
 
     pingpong_min_streams = 32    # fewer streams than this: one call at a time (a half would leave the GPU under-filled)
+    draw_ahead = True            # few streams with followers: draw the next call's tables while the GPU runs the current one
+
+    @staticmethod
+    def _next_depth(depth, cur, stats, base):
+        """Followers pay while the predictions hold: with p of them right a chain keeps ~1/(1-p) UTRs, the rest is
+        discarded work - the depth follows the share seen so far in this run (speed only)."""
+        n_pred = stats["predicted"] - base["predicted"]
+        if depth > 2 and n_pred >= 8:
+            p_ok = (stats["predicted_right"] - base["predicted_right"]) / n_pred
+            return depth if p_ok >= 0.75 else (max(2, depth // 2) if p_ok >= 0.5 else 2)
+        return cur
 
     @staticmethod
     def _streams_prepare(active, depth):
-        """Draw the tables of the next EM call: up to `depth` UTRs of every active stream (see _drive_streams)."""
+        """Draw the tables of the next EM call: up to `depth` UTRs of every active stream (see _drive_streams).
+        With depth > 1 the generator state after every sweep's own draws is kept, and the prune tables of a predicted
+        K' are drawn right behind the sweep's (also for the last UTR of a chain: the stream then stands where the
+        next call starts if the prediction holds)."""
         chains = [st[1][st[2]:st[2] + depth] for st in active]
         packs = [[] for _ in active]
         marks = [[] for _ in active]      # generator state after each sweep's own draws
@@ -916,7 +961,7 @@ class Engine:
                 packs[si].append(pk)
                 marks[si].append(smp.state.copy() if depth > 1 else None)
                 pre = None
-                if pos + 1 < len(chains[si]):
+                if depth > 1:
                     pred = sw.pred if sw.best is None else "stop"      # a re-run's sweep has no prediction of its own
                     if pred == "stop":
                         chains[si] = chains[si][:pos + 1]
@@ -928,12 +973,13 @@ class Engine:
 
     @staticmethod
     def _streams_absorb(active, prepared, out, deferred, on_done):
-        """Take the results of one EM call in stream order, as far as the predictions held; returns the streams that
-        still have UTRs."""
+        """Take the results of one EM call in stream order, as far as the predictions held.  Returns (the streams that
+        still have UTRs, per stream of `active`: did every prediction of its chain hold - the generator then stands
+        where _streams_prepare left it)."""
         pj, chains, packs, marks, ahead = prepared
         stats = Engine.spec_stats
         stats["calls"] += 1
-        lo, nxt = 0, []
+        lo, nxt, held = 0, [], []
         for st, ch, ps, mk, ah in zip(active, chains, packs, marks, ahead):
             smp, live = st[0], True
             for j, (sw, pk) in enumerate(zip(ch, ps)):
@@ -951,7 +997,7 @@ class Engine:
                 if not last:
                     stats["predicted"] += 1
                 if sw.done:                            # clean end
-                    if pre is not None:                # ... but the followers were drawn past a prune's draws
+                    if pre is not None:                # ... but what follows was drawn past a prune's draws
                         smp.state[:] = mk[j]
                         live = False
                 elif sw.stage == "prune" and sw.trace is None and Engine.defer_prunes:
@@ -959,23 +1005,24 @@ class Engine:
                     if pre is not None and pre[0] == sw.prune_K():
                         deferred.append((sw, sw.make_packed(predrawn=pre[1:])))
                     else:
-                        if not last:
+                        if mk[j] is not None:
                             smp.state[:] = mk[j]
                             live = False
                         deferred.append((sw, sw.make_packed()))
                 else:                                  # a re-run sweep (or a traced prune): stays the head of its stream
-                    if not last:
+                    if mk[j] is not None:
                         smp.state[:] = mk[j]
-                        live = False
+                    live = False
                     continue
                 if live and not last:
                     stats["predicted_right"] += 1
                 st[2] += 1
                 if on_done is not None:
                     on_done(sw)
+            held.append(live)
             if st[2] < len(st[1]):
                 nxt.append(st)
-        return nxt
+        return nxt, held
 
     @staticmethod
     def _drive(batch, sweeps, deferred=None):

@@ -28,6 +28,6 @@ for depth in (1, 2, 4, 8, 12, 16, 24, 32):
     d = {k: (Engine.spec_stats[k] - b[k]) // 2 for k in b}
     sig = [(r.fit.K, tuple(r.fit.a_idx), tuple(r.fit.ws), r.n_jobs) for r in res]
     ref = ref or sig
-    print(f"depth {depth:2d}: {U / dt:7.1f} UTRs/s  {dt * 1e3 / U:.2f} ms/UTR  calls {d['calls']}  kept {d['utrs_kept']}  discarded {d['utrs_discarded']}  predictions {d['predicted_right']}/{d['predicted']}  identical {sig == ref}", flush=True)
+    print(f"depth {depth:2d}: {U / dt:7.1f} UTRs/s  {dt * 1e3 / U:.2f} ms/UTR  calls {d['calls']}  kept {d['utrs_kept']}  discarded {d['utrs_discarded']}  predictions {d['predicted_right']}/{d['predicted']}  drawn ahead {d['calls_drawn_ahead']}  identical {sig == ref}", flush=True)
 nj = np.array([r.n_jobs for r in res])
 print("job counts per UTR:", dict(zip(*np.unique(nj, return_counts=True))))
