@@ -1357,6 +1357,12 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             if (executed == executed_prev) break;
             executed_prev = executed;
         }
+        if (debug && r < nround) {      // cumulative tensor bytes the M-step has asked for (its own tally), per round
+            unsigned long long shard[64], tb = 0;
+            HIPCHK(hipMemcpy(shard, c->d_counters.as<unsigned long long>() + CNT_MSTEP_TENSOR, sizeof(shard), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 64; ++i) tb += shard[i];
+            fprintf(stderr, "[em bytes %d] %llu\n", r, tb);
+        }
         if (debug && (r == 0 || r == 10 || r == 25 || r == nround - 1)) {
             unsigned long long h[16];
             HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));

@@ -15,6 +15,8 @@ plan=eng.plan(preps,[(20250225+i)%2**32 for i in range(U)])
 b=HipBatch(eng.ctx,preps)
 eng.process(b,preps,plan,False)
 os.environ["SCAPE_HIP_ROUND_TIMING"]="1"; os.environ["SCAPE_HIP_ROUND_TRACE"]="1"
+if len(sys.argv) > 1 and sys.argv[1] == "bytes":
+    os.environ["SCAPE_HIP_DEBUG"]="1"       # also: the M-step's cumulative tensor bytes after every round (synchronises each round)
 eng.ctx.lib.scape_hip_timing_reset(eng.ctx.h)
 b.build(); out=b.em_packed(plan["main"])
 eng.ctx.lib.scape_hip_timing_reset(eng.ctx.h)
