@@ -379,3 +379,91 @@ def test_wave_split_respects_budget(monkeypatch):
     assert waves == [[0], [1, 2]]
     with pytest.raises(Exception):
         eng.waves(preps)
+
+
+# ---------------------------------------------------------------- exact-stream driver (host logic only, no GPU)
+class _FakeBatch:
+    """Stands in for HipBatch.em_packed in the stream-driver tests: every job's "fit" is a pure function of that job's
+    own table row (as on the GPU, where a job's bits do not depend on what shares its call), made up so that sweeps end
+    clean, pruned to various K' or at K = n_max (re-run)."""
+    calls = 0
+
+    def em_packed(self, pj, reuse_buffers=False, want_lb=True):
+        import zlib
+        from scape_amd.host import N_ROUND
+        type(self).calls += 1
+        n, kmax = len(pj), pj.kmax
+        ao, bo, wo = pj.a.copy(), pj.b.copy(), np.zeros_like(pj.w)
+        bic, nlb, lb = np.zeros(n), np.full(n, 3, np.int32), np.zeros((n, N_ROUND))
+        for i in range(n):
+            K = int(pj.jk[i])
+            h = zlib.crc32(pj.a[i, :K].tobytes() + pj.b[i, :K].tobytes() + pj.w[i, :K + 1].tobytes() + pj.ka[i].tobytes() +
+                           bytes([K, int(pj.jf[i])]))          # (the row up to K: the padding width depends on the call)
+            r = np.random.RandomState(h)
+            w = r.dirichlet(np.full(K + 1, 0.6))
+            w[0] += 0.06                                   # (one component always stays: rm_component needs K' >= 1)
+            w /= w.sum()
+            wo[i, :K + 1] = w
+            bic[i] = 2.0 * abs(K - 2.3) + 30.0 * r.random_sample()
+            lb[i, :3] = r.random_sample(3)
+        return ao, bo, wo, bic, nlb, lb
+
+
+def _stream_preps(n, base):
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    return [prepare_utr(df, gene_info_str=g, n_max_apa=3, n_min_apa=1)
+            for g, df, _ in (synth_utr(i, 150, k_cap=3, base_seed=base) for i in range(n))]
+
+
+def _drive(chunks, depth, preds=None, seed=7):
+    from scape_amd.engine import Engine, _Sweep
+    from scape_amd.host import FastSampler
+    streams, all_sw = [], []
+    for ci, preps in enumerate(chunks):
+        smp = FastSampler(np.random.RandomState(seed + ci))
+        sws = [_Sweep(u, q, smp, True) for u, q in enumerate(preps)]
+        if preds is not None:
+            for sw, p in zip(sws, preds[ci]):
+                sw.pred = p
+        streams.append((smp, sws))
+        all_sw.append(sws)
+    deferred = []
+    Engine._drive_streams(_FakeBatch(), streams, deferred, depth=depth)
+    Engine._finish_deferred(_FakeBatch(), deferred)
+    sig = [[(sw.best.K, sw.best.a_idx.tobytes(), sw.best.b_idx.tobytes(), sw.best.ws.tobytes(), sw.best.bic, sw.n_jobs)
+            for sw in sws] for sws in all_sw]
+    return sig, [smp.state.copy() for smp, _ in streams]
+
+
+def test_stream_driver_results_do_not_depend_on_depth_or_predictions(monkeypatch):
+    """Engine._drive_streams: several UTRs of a stream per EM call, drawn from the state their predecessors' PREDICTED
+    outcome leaves.  Whatever the predictions say - right, wrong, absent, 'stop' - every UTR must get the fit, the job
+    count and the generator state of the strictly serial loop (depth 1); also with the look-ahead draws on and off and in the
+    two-halves schedule of many streams."""
+    from scape_amd.engine import Engine
+    chunks = [_stream_preps(14, 9100), _stream_preps(9, 9200), _stream_preps(5, 9300)]
+    ref, ref_states = _drive(chunks, 1)
+    outcomes = {(k, nj) for ch in ref for (k, *_rest, nj) in ch}
+    assert len({nj for _k, nj in outcomes}) >= 3, outcomes          # clean (30 jobs), pruned (+1) and re-run sweeps all occur
+    rs = np.random.RandomState(3)
+    true_pred = [[("clean" if nj == 30 else ("prune", k) if nj == 31 else "stop") for (k, *_r, nj) in ch] for ch in ref]
+    for trial in range(6):
+        if trial == 0:
+            preds = None                                              # no predictor: followers assume a clean end
+        elif trial == 1:
+            preds = true_pred                                         # an oracle predictor: (almost) nothing discarded
+        else:                                                         # right, wrong and missing predictions mixed
+            preds = [[p if rs.random_sample() < 0.6 else rs.choice(["clean", "stop", None, "p1", "p2"]) for p in ch]
+                     for ch in true_pred]
+            preds = [[("prune", int(p[1])) if isinstance(p, str) and p.startswith("p") else p for p in ch] for ch in preds]
+        for depth, ahead, pp in ((3, True, 32), (8, True, 32), (8, False, 32), (4, True, 2)):
+            monkeypatch.setattr(Engine, "draw_ahead", ahead)
+            monkeypatch.setattr(Engine, "pingpong_min_streams", pp)
+            before = dict(Engine.spec_stats)
+            got, states = _drive(chunks, depth, preds)
+            assert got == ref, (trial, depth, ahead, pp)
+            for a, b in zip(states, ref_states):
+                assert np.array_equal(a, b), (trial, depth, ahead, pp)
+            if trial == 1 and pp == 32:
+                assert Engine.spec_stats["utrs_kept"] - before["utrs_kept"] >= sum(len(c) for c in chunks)
