@@ -976,7 +976,9 @@ struct DevBuf {
         // size, and re-allocating tens of GB for each of them costs more than the batch itself
         // (large buffers get it from the start: device memory costs ~25 ms per GB to allocate, and the second batch of a
         // stream is a few per cent larger than the first as often as not)
-        const bool regrow = p != nullptr || bytes > ((size_t)1 << 30);
+        // - not the very large ones: engines that share a device size their batches to a fraction of what is free, and
+        //   12 % on top of each pushed two worker processes on one GPU over the edge (one of them ran 3x slower)
+        const bool regrow = p != nullptr || (bytes > ((size_t)1 << 30) && bytes <= ((size_t)48 << 30));
         if (p) {
             (void)hipFree(p);
             p = nullptr;
