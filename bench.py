@@ -137,7 +137,8 @@ def parity_count(preps, plan, res, outs):
         else:
             same += (fit.K == K and np.array_equal(q.theta[fit.a_idx], alpha[j, :K])
                      and np.array_equal(q.betas[fit.b_idx], beta[j, :K])
-                     and np.allclose(fit.ws, ws[j, :K + 1], rtol=1e-4, atol=1e-9))
+                     and np.allclose(fit.ws, ws[j, :K + 1], rtol=1e-4, atol=1e-9)
+                     and abs(fit.bic - bic[j]) <= 1e-8 * abs(bic[j]))
     return int(same)
 
 

@@ -907,6 +907,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em(
 }
 
 #include "em_lockstep.inc"
+#include "mstep_ring.inc"
 
 // ------------------------------------------------------------------------------------------
 // labels: get_label (apa_core.py:873-881), one workgroup per selected model
@@ -1031,7 +1032,7 @@ struct scape_hip_ctx {
     DevBuf l_utr, l_K, l_a, l_b, l_ws, l_labels;
     // lock-step EM state (em_lockstep.inc)
     DevBuf e_ia, e_ib, e_sia, e_sib, e_ws, e_slw, e_lb, e_ell, e_nlb, e_status, e_rdk, e_rdlo, e_rdhi, e_rdm,
-        e_rdlw, e_rdsv, e_rdn0, e_rdn1, e_V, e_Vsuf, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist, e_active;
+        e_rdlw, e_rdsv, e_rdn0, e_rdn1, e_V, e_Vsuf, e_voff, e_ptscore, e_ptrow, e_ptoff, e_ujoff, e_ujlist, e_active, e_elist;
     std::vector<EventPair> ev[6];
     double ms_acc[6] = {0, 0, 0, 0, 0, 0};
     int n_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1134,8 +1135,12 @@ static int launch_phase_b(scape_hip_ctx *c, const DevParams &prm, int n_utr, int
                        (size_t)16 * (((Wmax + 3) & ~3) + 1) * sizeof(double);
     if (lds > 150 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
     dim3 grid((unsigned)(((n_utr + 7) / 8) * 8 * T_max));
-    const char *pe = getenv("SCAPE_HIP_PB_PROBE");   // timing probe (results are wrong with it): 1 no log path, 2 no linear path, 4 no G exps
+#ifdef SCAPE_HIP_TOOLS   // tools-only builds (-DSCAPE_HIP_TOOLS): timing probe that switches parts of Phase B off - results are wrong with it
+    const char *pe = getenv("SCAPE_HIP_PB_PROBE");   // 1 no log path, 2 no linear path, 4 no G exps
     const int probe = pe ? atoi(pe) : 0;
+#else
+    const int probe = 0;
+#endif
     if (prm.B <= 16)
         hipLaunchKernelGGL(k_phase_b<16>, grid, dim3(256), lds, c->stream, d_desc, prm, d_r, d_pa, d_theta,
                            d_loglist, d_AT, d_V, d_M, Wmax, all_log, c->d_err.as<int>(), n_utr, T_max, d_tile_nend, probe);
@@ -1184,6 +1189,16 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     std::vector<int32_t> active;
     for (int u = 0; u < c->n_utr; ++u)
         if (ujoff[u + 1] > ujoff[u]) active.push_back(u);
+    // Blocks are dealt round-robin over the 8 XCDs and the M-step gives XCD x the UTRs at positions x, x + 8, ... of this
+    // list: sorted by tensor size, the 8 UTRs that are in flight side by side are of one size class (their tiles take
+    // alike) and every XCD gets the same mix - in index order an XCD that drew the large UTRs finishes last while
+    // the others idle.  Placement only: a UTR's results do not depend on where or next to what it runs.
+    const bool size_order = !getenv("SCAPE_HIP_NO_SIZE_ORDER") && !getenv("SCAPE_HIP_TWO_STREAMS");
+    if (size_order)
+        std::stable_sort(active.begin(), active.end(), [&](int32_t a, int32_t b) {
+            const UtrDesc &da = c->h_desc[a], &db = c->h_desc[b];
+            return (int64_t)da.T * da.Np > (int64_t)db.T * db.Np;
+        });
     const int n_active = (int)active.size();
     int max_jobs_utr = 1;
     for (int u : active) max_jobs_utr = std::max<int>(max_jobs_utr, (int)(ujoff[u + 1] - ujoff[u]));
@@ -1197,6 +1212,10 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     const int split_maxtiles = env_r ? atoi(env_r) : 1024, wide_maxjobs = env_w ? atoi(env_w) : 1024;
     const bool wide = n_jobs <= wide_maxjobs && kmax + 1 <= 16;   // E-step: 4 wavefronts per job (k2_estep_cs)
     const bool job_split = (long long)n_active * tiles_max <= split_maxtiles;
+    // M-step kernel: k3_mstep (LDS-DMA rings, mstep_ring.inc) unless SCAPE_HIP_MSTEP=v2 asks for the register-staged
+    // k2_mstep (A/B runs; identical bits).  k3's DMA source offsets are 32-bit byte offsets from the start of the job vectors.
+    const char *env_m = getenv("SCAPE_HIP_MSTEP");
+    bool ring_mstep = !(env_m && strcmp(env_m, "v2") == 0);
     constexpr int pt_rows = MT_ROWS;
     size_t vtot = 0, pttot = 0;
     for (size_t j = 0; j < nj; ++j) {
@@ -1215,6 +1234,21 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         c->e_ptscore.ensure(pttot * 8) || c->e_ptrow.ensure(pttot * 4) || c->e_ptoff.ensure(nj * 8) ||
         c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4) || c->e_active.ensure((size_t)c->n_utr * 4))
         return 1;
+    if (vtot * 8 >= ((size_t)1 << 31)) ring_mstep = false;
+    if (ring_mstep && M3_LDS_BYTES > 64 * 1024)   // per device; a few microseconds
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k3_mstep), hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES));
+    // The E-step gives XCD x the x-th eighth of its job list: with the jobs of UTR active[x], active[x + 8], ... there,
+    // every XCD gets the same mix of sizes, and the v vectors a UTR's jobs write are read by the M-step tiles of the same
+    // UTR on the same XCD (L2; speed only).
+    std::vector<int32_t> elist;
+    if (size_order && n_active >= 8) {
+        elist.reserve(nj);
+        for (int x = 0; x < 8; ++x)
+            for (int k = x; k < n_active; k += 8)
+                for (int64_t q = ujoff[active[k]]; q < ujoff[active[k] + 1]; ++q) elist.push_back(ujlist[q]);
+        if (c->e_elist.ensure(nj * 4)) return 1;
+        HIPCHK(hipMemcpyAsync(c->e_elist.p, elist.data(), nj * 4, hipMemcpyHostToDevice, c->stream));
+    }
     if (n_active) HIPCHK(hipMemcpyAsync(c->e_active.p, active.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->e_voff.p, voff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->e_ptoff.p, ptoff.data(), nj * 8, hipMemcpyHostToDevice, c->stream));
@@ -1249,8 +1283,8 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     unsigned long long *dbg = nullptr;
     const bool debug = getenv("SCAPE_HIP_DEBUG") != nullptr;
     if (debug) {
-        HIPCHK(hipMalloc((void **)&dbg, 16 * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIPCHK(hipMalloc((void **)&dbg, 24 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(dbg, 0, 24 * sizeof(unsigned long long), c->stream));
     }
     const bool fine = getenv("SCAPE_HIP_ROUND_TIMING") != nullptr;
     bool any_m = false;   // fixed-inference jobs (mstep_fixed) have no grid arg-max
@@ -1308,7 +1342,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             const int ngj = (int)(j1 - j0);
             if (ngj == 0) continue;
             hipStream_t st = g_stream[g];
-            const int32_t *jl = c->e_ujlist.as<int32_t>() + j0;
+            const int32_t *jl = elist.empty() ? c->e_ujlist.as<int32_t>() + j0 : c->e_elist.as<int32_t>();
             if (fine && ev_begin(c, 4)) return 1;
 #define LAUNCH_E(KERNEL, CM, THREADS)                                                                          \
     hipLaunchKernelGGL(KERNEL<CM>, dim3((unsigned)(((ngj + 7) / 8) * 8)), dim3(THREADS), 0, st,                \
@@ -1338,11 +1372,15 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                 // few live tiles: passes of 16 jobs, one workgroup each (gridDim.y covers the longest job list of a UTR)
                 const int jobs_per_pass = job_split ? 16 : MT_MAXJ;
                 const unsigned psplit = job_split ? (unsigned)std::min(64, (max_jobs_utr + 15) / 16) : 1u;
-                hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max), psplit), dim3(256), 0, st,
-                                   c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, tiles_max,
-                                   c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo,
-                                   S.rd_hi, S.rd_lw, S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row,
-                                   c->d_tile_nend.as<int32_t>(), c->d_counters.as<unsigned long long>(), jobs_per_pass, dbg);
+#define MSTEP_ARGS c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, tiles_max,           \
+                   c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw,  \
+                   S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, c->d_tile_nend.as<int32_t>(),                    \
+                   c->d_counters.as<unsigned long long>(), jobs_per_pass, dbg
+                if (ring_mstep)
+                    hipLaunchKernelGGL(k3_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max), psplit), dim3(256), M3_LDS_BYTES, st, MSTEP_ARGS);
+                else
+                    hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max), psplit), dim3(256), 0, st, MSTEP_ARGS);
+#undef MSTEP_ARGS
                 c->h_traffic[3] += 1;
                 HIPCHK(hipGetLastError());
                 if (fine && ev_end(c, 5)) return 1;
@@ -1366,12 +1404,14 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             fprintf(stderr, "[em bytes %d] %llu\n", r, tb);
         }
         if (debug && (r == 0 || r == 10 || r == 25 || r == nround - 1)) {
-            unsigned long long h[16];
+            unsigned long long h[24];
             HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            // k3_mstep only: k-steps x jobs if every job stopped at its own support / as run (16-job groups over the union)
+            fprintf(stderr, "[em round %d] job-halfchunks own-support %llu, union %llu, padded to groups %llu; sorted-by-n1 groups %llu\n", r, h[16], h[17], h[18], h[19]);
             fprintf(stderr, "[em round %d] tiles %llu active %llu sum_cnt %llu passes %llu | G-hist:", r, h[0], h[1], h[2], h[3]);
             for (int i = 4; i < 16; ++i) fprintf(stderr, " %llu", h[i]);
             fprintf(stderr, "\n");
-            HIPCHK(hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), c->stream));
+            HIPCHK(hipMemsetAsync(dbg, 0, 24 * sizeof(unsigned long long), c->stream));
         }
     }
     if (split) {
@@ -1429,7 +1469,7 @@ int scape_hip_batch_free(scape_hip_ctx *c) {
                      &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels, &c->e_ia, &c->e_ib, &c->e_sia, &c->e_sib,
                      &c->e_ws, &c->e_slw, &c->e_lb, &c->e_ell, &c->e_nlb, &c->e_status, &c->e_rdk, &c->e_rdlo,
                      &c->e_rdhi, &c->e_rdm, &c->e_rdlw, &c->e_rdsv, &c->e_rdn0, &c->e_rdn1, &c->e_V, &c->e_Vsuf, &c->e_voff, &c->e_ptscore,
-                     &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist, &c->e_active, &c->j_sel, &c->j_lbsel};
+                     &c->e_ptrow, &c->e_ptoff, &c->e_ujoff, &c->e_ujlist, &c->e_active, &c->e_elist, &c->j_sel, &c->j_lbsel};
     for (DevBuf *b : all) b->release();
     c->last_em_jobs = 0;
     c->loaded = c->built = c->build_unchecked = false;
@@ -1530,6 +1570,7 @@ int scape_hip_get_loglik_marginal_tensor(scape_hip_ctx *c, const double *all_the
     if (B < 1 || B > SCAPE_MAX_BETA) return fail("n_beta out of range");
     if (!all_theta || !betas || !A || !out) return fail("NULL argument");
     CTX_ENTER(c);
+    if (finish_build(c)) return 1;   // this call reuses the handle's error word: read a queued build's flag first
     for (int i = 1; i < T; ++i)
         if (!(all_theta[i] >= all_theta[i - 1])) return fail("all_theta must be ascending");
     DevParams P;
@@ -1689,6 +1730,7 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
     if (!c->loaded) return fail("no batch loaded");
     CTX_ENTER(c);
+    if (finish_build(c)) return 1;   // a second build on the handle must not wipe the first one's pending flag
     dim3 grid((c->Np_max + 255) / 256, c->T_max, c->n_utr);
     if (ev_begin(c, 0)) return 1;
     hipLaunchKernelGGL(k_phase_a, grid, dim3(256), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm, c->d_x.as<double>(),
@@ -1822,6 +1864,7 @@ int scape_hip_batch_em_fetch_lb(scape_hip_ctx *c, int32_t n_sel, const int32_t *
     if (!c) return fail("ctx is NULL");
     if (n_sel < 1 || !job_idx || !lb_out) return fail("fetch_lb: bad arguments");
     CTX_ENTER(c);
+    if (finish_build(c)) return 1;
     if (c->last_em_jobs < 1) return fail("fetch_lb: no completed scape_hip_batch_em call on this handle");
     for (int i = 0; i < n_sel; ++i)
         if (job_idx[i] < 0 || job_idx[i] >= c->last_em_jobs) return fail("fetch_lb: job index out of range");

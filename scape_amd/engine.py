@@ -840,7 +840,22 @@ class Engine:
         if len(preps) < 2 or any(q.fixed_run for q in preps):
             return                                    # fixed_run ends clean by construction (:1009-1017)
         plan = self.plan(preps, [(Engine.spec_seed + 7919 * i) % (2 ** 32) for i in range(len(preps))])
-        out = self.process(batch, preps, plan, re_run_mode=False, build=False, labels=False)
+        # The pass is a guess from OTHER seeds: whatever goes wrong in it (every component of some UTR pruned away ->
+        # the reference's IndexError; a library error from the extra wave-wide job tables) must not end a stream whose
+        # real fits would finish, and it must not overwrite the measurement fields of the real sweeps.
+        keep = {k: getattr(self, k, None) for k in ("last_main_em_ms", "last_main_counters", "last_host_ms")}
+        try:
+            out = self.process(batch, preps, plan, re_run_mode=False, build=False, labels=False)
+        except (IndexError, _lib.ScapeHipError):
+            for sw in sweeps:
+                sw.pred = None
+            return
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    self.__dict__.pop(k, None)
+                else:
+                    setattr(self, k, v)
         for sw, (fit, _lab, nj) in zip(sweeps, out):
             n_sweep = (sw.n_max - sw.n_min + 1) * N_TRIAL
             if re_run_mode and fit.K == sw.n_max:

@@ -655,32 +655,47 @@ def test_config2_full_size_every_utr_vs_cpu_port(oracle):
         assert 1 <= fit.K <= 5 and len(lab) == q.N and abs(fit.ws.sum() - 1) < 1e-12
 
 
-def test_headline_shape_every_utr_vs_cpu_port(oracle):
-    """BASELINE config #3 (the headline) shape: 64 UTRs x 2,000 reads, K = 1..10 x 10 restarts = 6,400 EM jobs in
-    one resident batch through Engine.process; the CPU port (oracle) runs the same 100 jobs of EVERY UTR and goes
-    through the reference's selection and pruning rule; all 64 pA calls must agree (K, alpha, beta; ws to 1e-4
-    where no re-fit is involved)."""
-    import bench
+def _assert_parameters_equal_oracle(paras, outs, ws_rtol=1e-6):
+    """Every field of the final Parameters the reference's consumers read, GPU vs oracle.pool:
+    K, alpha, beta and ALL per-read labels exact; ws (also the re-fitted ws of a pruned UTR), bic and the lower-bound
+    trace of the final fit (length exact = same number of EM rounds)."""
+    for a, o in zip(paras, outs):
+        g = o["gene"]
+        assert a.gene_info_str == g
+        assert a.K == o["K"], (g, a.K, o["K"])
+        assert np.array_equal(a.alpha_arr, o["alpha"]), (g, a.alpha_arr, o["alpha"])
+        assert np.array_equal(a.beta_arr, o["beta"]), (g, a.beta_arr, o["beta"])
+        assert np.array_equal(a.label_arr, o["labels"]), (g, int((a.label_arr != o["labels"]).sum()))
+        assert np.allclose(a.ws, o["ws"], rtol=ws_rtol, atol=1e-10), (g, a.ws, o["ws"])
+        assert a.bic == pytest.approx(o["bic"], rel=1e-9), (g, a.bic, o["bic"])
+        assert len(a.lb_arr) == len(o["lb"]), (g, len(a.lb_arr), len(o["lb"]))
+        assert np.allclose(np.array(a.lb_arr), o["lb"], rtol=1e-9), g
+
+
+def test_headline_shape_every_utr_vs_oracle(oracle):
+    """BASELINE config #3 (the headline) shape: 64 UTRs x 2,000 reads of the bench's own stream, K = 10..1 x 10 restarts
+    (6,400 EM jobs + prune re-fits + re-run sweeps) through the batched product path with re_run_mode = True (the
+    reference's default, input_processor.py:97-112).  The oracle fits EVERY UTR in full (subsample_run: selection,
+    rm_component re-fit, get_label, re-run loop) from the same per-UTR seed; all final fields must agree - K, alpha, beta and
+    every per-read label exactly, ws / bic / lb_arr to rounding."""
+    from oracle.pool import fit_many
+    from scape_amd.apa_core import to_parameters
     from scape_amd.engine import Engine
     from scape_amd.host import prepare_utr
     from scape_amd.synth import synth_utr
-    U, kw = 64, dict(n_max_apa=10, n_min_apa=1)
+    U, kw, seed = 64, dict(n_max_apa=10, n_min_apa=1), 20250225
     preps = []
     for i in range(U):
-        g, df, _ = synth_utr(i, 2000, k_cap=10, base_seed=20250225)      # the bench's own stream
+        g, df, _ = synth_utr(i, 2000, k_cap=10, base_seed=seed)      # the bench's own stream
         preps.append(prepare_utr(df, gene_info_str=g, **kw))
     eng = Engine()
-    plan = eng.plan(preps, [(20250225 + i) % 2 ** 32 for i in range(U)])
-    assert len(plan["main"]) == 100 * U and plan["main"].kmax == 10
-    batch = eng.load(preps)
-    res = eng.process(batch, preps, plan, re_run_mode=False)
-    cores = min(16, os.cpu_count() or 1)
-    cb, outs = bench.cpu_baseline(preps, plan, 1e9, cores)          # target time = infinity: every UTR
-    assert len(outs) == U
-    assert bench.parity_count(preps, plan, res, outs) == U
-    for (fit, lab, nj), q in zip(res, preps):
-        assert 1 <= fit.K <= 10 and len(lab) == q.N and abs(fit.ws.sum() - 1) < 1e-12
-    batch.free()
+    res = eng.run(preps, rng_mode="per_utr", seed=seed, re_run_mode=True)
+    outs = fit_many([(i, 2000, 10, seed, (seed + i) % 2 ** 32, True, kw) for i in range(U)])
+    _assert_parameters_equal_oracle([to_parameters(r) for r in res], outs)
+    pruned = sum(o["n_calls"] % 10 == 1 for o in outs)           # sweeps are multiples of 10 calls, a prune re-fit adds one
+    assert pruned >= U // 4, pruned            # the re-fitted ws of pruned UTRs is part of what was compared
+    for r, q in zip(res, preps):
+        assert 1 <= r.fit.K and len(r.labels_bin) == q.N and abs(r.fit.ws.sum() - 1) < 1e-12
 
 
 def test_small_call_shapes_give_identical_bits(hip_ctx):
@@ -872,18 +887,26 @@ def test_pipelined_per_utr_mode_equals_engine_run(tmp_path, oracle):
             assert np.array_equal(a.label_arr, ref.label_arr)
 
 
-@pytest.mark.parametrize("reads,kcap,n", [(10000, 10, 2), (5000, 12, 2)])
+@pytest.mark.parametrize("reads,kcap,n", [(10000, 10, 16), (5000, 12, 16)])
 def test_deep_pileup_shapes_vs_oracle(oracle, reads, kcap, n):
-    """BASELINE configs #4 (10k reads, K<=10) and #5 (5k reads, K=1..12) shapes, two UTRs each, every job
-    checked against the oracle through the per-UTR RNG mode."""
+    """BASELINE configs #4 (10k reads, K<=10) and #5 (5k reads, K=1..12) shapes - the 16-column E-step variant and
+    2,154-bin tiles are the product path there.  16 UTRs per shape through the batched path (re_run_mode on) against
+    the oracle's full fit of every UTR (all final fields, every label); for the first two UTRs also every single
+    em_algo call against the oracle's call trace."""
+    from oracle.pool import fit_many
     from scape_amd.apa_core import to_parameters
     from scape_amd.engine import Engine
     from scape_amd.host import prepare_utr
     from scape_amd.synth import synth_chunk
-    chunk = synth_chunk(n, reads, k_cap=min(kcap, 5), base_seed=31337 + reads)
+    base = 31337 + reads
+    chunk = synth_chunk(n, reads, k_cap=min(kcap, 5), base_seed=base)
     kw = dict(n_max_apa=kcap, n_min_apa=1)
     preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in chunk]
     eng = Engine(device=0)
+    full = eng.run(preps, rng_mode="per_utr", seed=5, re_run_mode=True)
+    outs = fit_many([(i, reads, min(kcap, 5), base, 5 + i, True, kw) for i in range(n)])
+    _assert_parameters_equal_oracle([to_parameters(r) for r in full], outs)
+    chunk, preps = chunk[:2], preps[:2]
     res = eng.run(preps, rng_mode="per_utr", seed=5, re_run_mode=False, keep_trace=True)
     for i, ((g, df), r) in enumerate(zip(chunk, res)):
         np.random.seed(5 + i)

@@ -467,3 +467,30 @@ def test_stream_driver_results_do_not_depend_on_depth_or_predictions(monkeypatch
                 assert np.array_equal(a, b), (trial, depth, ahead, pp)
             if trial == 1 and pp == 32:
                 assert Engine.spec_stats["utrs_kept"] - before["utrs_kept"] >= sum(len(c) for c in chunks)
+
+
+def test_prediction_pass_failure_is_not_a_stream_failure():
+    """Engine._predict_outcomes fits the wave from OTHER seeds; when that fit prunes every component of some UTR
+    (the reference's IndexError, apa_core.py:838-839) or the library refuses its job tables, the real stream must go
+    on without predictions and the measurement fields of the real sweeps must stay as they were."""
+    from scape_amd import _lib
+    from scape_amd.engine import Engine, _Sweep
+    from scape_amd.host import FastSampler
+    preps = _stream_preps(4, 9400)
+    for exc in (IndexError("index 0 is out of bounds for axis 0 with size 0"), _lib.ScapeHipError("job table refused")):
+        eng = Engine.__new__(Engine)              # no GPU: only the prediction wrapper is exercised
+        eng.last_main_em_ms, eng.last_main_counters = 12.5, (1, 2, 3)
+
+        def boom(*a, _e=exc, **k):
+            eng.last_main_em_ms, eng.last_host_ms = -1.0, dict(x=1)      # what a half-finished process() leaves behind
+            raise _e
+        eng.plan = lambda preps, seeds: None
+        eng.process = boom
+        smp = FastSampler(np.random.RandomState(1))
+        sweeps = [_Sweep(u, q, smp, True) for u, q in enumerate(preps)]
+        for sw in sweeps:
+            sw.pred = "clean"
+        eng._predict_outcomes(None, preps, sweeps, True)
+        assert all(sw.pred is None for sw in sweeps)
+        assert eng.last_main_em_ms == 12.5 and eng.last_main_counters == (1, 2, 3)
+        assert not hasattr(eng, "last_host_ms")
