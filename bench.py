@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--kcap", type=int, default=10)
     ap.add_argument("--base-seed", type=int, default=20250225)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the two-step legs at BASELINE configs #2 / #4 / #5")
+    ap.add_argument("--no-cli-leg", action="store_true", help="skip the fresh-process `scape infer_pa` leg")
     ap.add_argument("--e2e-utrs", type=int, default=50000,
                     help="UTRs of the untimed-by-the-metric end-to-end leg (chunk files -> .res.pkl), 0 = skip; "
                          "default = the whole headline job")
@@ -63,7 +65,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(preps, plan, target_s, cores):
+def cpu_baseline(preps, plan, target_s, cores, max_utrs=None):
     """The oracle (CPU restatement of the reference algorithm, 'port') on a bounded sample of the
     same workload: Phase A + Phase B + the same EM jobs per UTR, UTRs spread over `cores` threads."""
     from oracle import scape_oracle as so
@@ -105,12 +107,14 @@ def cpu_baseline(preps, plan, target_s, cores):
     first = one(0)
     t1 = time.perf_counter() - t0
     n = int(min(len(preps) - 1, max(cores, round(cores * target_s / max(t1, 1e-3)))))
+    if max_utrs is not None:
+        n = min(n, int(max_utrs))
     n = max(n, 1)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         outs = list(ex.map(one, range(1, 1 + n)))
     dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="UTRs/s", cores=cores, kind="port",
+    return dict(value=n / dt, unit="UTRs/s", cores=cores, kind="port", single_thread_value=1.0 / t1,
                 sample=f"{n} UTRs of the same batch (Phase A+B + the same {int(spans[1] - spans[0])} EM jobs/UTR) "
                        f"on {cores} threads, {dt:.1f} s wall; 1 UTR on 1 thread = {t1:.2f} s"), [first] + outs
 
@@ -142,6 +146,49 @@ def parity_count(preps, plan, res, outs):
     return int(same)
 
 
+def physical_cores():
+    """(physical cores among the CPUs this process may run on, threads per core) - /proc/cpuinfo's (physical id,
+    core id) pairs; falls back to usable CPUs / 2 when SMT is active and the pairs are not listed."""
+    try:
+        usable = set(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = set(range(os.cpu_count() or 1))
+    pairs, cur = set(), {}
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if ":" in line:
+                    k, v = (t.strip() for t in line.split(":", 1))
+                    cur[k] = v
+                elif not line.strip():
+                    if cur.get("processor", "").isdigit() and int(cur["processor"]) in usable and "core id" in cur:
+                        pairs.add((cur.get("physical id", "0"), cur["core id"]))
+                    cur = {}
+        if cur.get("processor", "").isdigit() and int(cur["processor"]) in usable and "core id" in cur:
+            pairs.add((cur.get("physical id", "0"), cur["core id"]))
+    except OSError:
+        pass
+    if pairs:
+        return len(pairs), max(1, round(len(usable) / len(pairs)))
+    smt = False
+    try:
+        with open("/sys/devices/system/cpu/smt/active") as fh:
+            smt = fh.read().strip() == "1"
+    except OSError:
+        pass
+    return max(1, len(usable) // (2 if smt else 1)), 2 if smt else 1
+
+
+def cgroup_cpu_limit():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max), None when unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def host_info():
     """What the CPU-side numbers were measured on (printed with cpu_baseline and the end-to-end legs)."""
     model = "unknown"
@@ -157,7 +204,9 @@ def host_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return dict(cpu_model=model, nproc=os.cpu_count() or 1, nproc_usable=usable)
+    cores, tpc = physical_cores()
+    return dict(cpu_model=model, nproc=os.cpu_count() or 1, nproc_usable=usable, physical_cores=cores,
+                threads_per_core=tpc, cgroup_cpu_limit=cgroup_cpu_limit())
 
 
 def write_synth_chunks(pool, root, n_utrs, reads, kcap, base_seed, per_file=128, first_index=10 ** 6):
@@ -240,6 +289,52 @@ def end_to_end(args, pool, dev):
                     includes="read+unpickle chunk files, binning, coverage peaks, restart sampling, H2D, Phase A/B, "
                              "EM sweep, BIC selection, prune re-fits, labels, Parameters, pickle write",
                     synth_write_s=t_write)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def cli_single_chunk(args):
+    """The reference's actual usage (input_processor.py:31, tutorial: one `scape infer_pa` process per chunk of 100
+    UTRs): a FRESH child process - interpreter start, imports, HIP context, device buffers, unpickling, binning, the
+    exact-stream fit, printing and pickling 100 Parameters - timed from outside, with the child's own stage clock
+    (SCAPE_TIMING_JSON) beside it.  apa_core.py:107-147."""
+    import shutil
+    import subprocess
+    import tempfile
+    from scape_amd.pipeline import synth_chunk_file
+    if args.no_cli_leg:
+        return None
+    root = tempfile.mkdtemp(prefix="scape_cli_")
+    try:
+        os.makedirs(os.path.join(root, "pkl_input"))
+        f = os.path.join(root, "pkl_input", "synth.100.1.1.input.pkl")
+        synth_chunk_file((f, 5 * 10 ** 6, 100, args.reads, args.kcap, args.base_seed))
+        with open(os.path.join(root, "parameters.toml"), "w") as fh:
+            fh.write(f"n_max_apa = {args.kcap}\nn_min_apa = 1\nre_run_mode = true\n")
+        runs = []
+        for _ in range(2):                          # second run: page cache and code objects warm
+            tj = os.path.join(root, "timing.json")
+            env = dict(os.environ, SCAPE_TIMING_JSON=tj, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            t0 = time.perf_counter()
+            cp = subprocess.run([sys.executable, "-m", "scape", "infer_pa", "--pkl_input_file", f, "--output_dir", root],
+                                env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd=root)
+            dt = time.perf_counter() - t0
+            if cp.returncode != 0:
+                return dict(error=cp.stderr[-2000:])
+            with open(tj) as fh:
+                stages = json.load(fh)
+            runs.append((dt, stages))
+        res = os.path.join(root, "pkl_output", "synth.100.1.1.res.pkl")
+        dt, stages = min(runs, key=lambda r: r[0])
+        inside = sum(v for k, v in stages.items() if k.endswith("_s"))
+        return dict(seconds=dt, utrs=100, value=100 / dt, unit="UTRs/s", first_run_seconds=runs[0][0],
+                    stages_s={k: round(v, 3) for k, v in stages.items()},
+                    interpreter_start_and_exit_s=round(dt - inside, 3), output_bytes=os.path.getsize(res),
+                    command="python -m scape infer_pa --pkl_input_file <100 UTRs x %d reads> --output_dir D "
+                            "(parameters.toml: n_max_apa = %d, re_run_mode = true; rng_mode = reference, the default)" % (args.reads, args.kcap),
+                    note="fresh child process per run, wall clock from outside (best of 2; the first run also pays cold file "
+                         "and code-object caches); stages_s is the child's own clock: imports, HIP context + library, "
+                         "reading and preparing the chunk, the fit, printing + pickling the results")
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -401,20 +496,6 @@ def main():
     from scape_amd.host import prepare_utr
     from scape_amd.synth import synth_utr
 
-    U = args.utrs
-    kw = dict(n_max_apa=args.kcap, n_min_apa=1)
-    t_prep = time.perf_counter()
-    preps = []
-    for i in range(U):
-        gene, df, _truth = synth_utr(rank * U + i, args.reads, k_cap=args.kcap, base_seed=args.base_seed)
-        preps.append(prepare_utr(df, gene_info_str=gene, **kw))
-    eng = Engine(device=dev)
-    plan = eng.plan(preps, [(args.base_seed + rank * U + i) % 2 ** 32 for i in range(U)])
-    t_prep = time.perf_counter() - t_prep
-    t_h2d = time.perf_counter()
-    batch = HipBatch(eng.ctx, preps)            # inputs resident in HBM from here on
-    t_h2d = time.perf_counter() - t_h2d
-
     def sync_all():
         # every C-ABI call returns with its stream synchronised, so the device is idle here
         if dist is not None:
@@ -434,110 +515,167 @@ def main():
             dt = float(t.item())
         return dt, r
 
-    em_ms = [0.0]
-
-    def step():
-        r = eng.process(batch, preps, plan, re_run_mode=False)
-        em_ms[0] += eng.last_main_em_ms
-        return r
-
-    for _ in range(args.warmup):
-        res = step()
+    eng = Engine(device=dev)
     lib, h = eng.ctx.lib, eng.ctx.h
-    lib.scape_hip_timing_reset(h)
-    em_ms[0] = 0.0
-    elapsed, res = timed(step, args.steps)
 
-    # kernel timing (HIP events on the library's stream) of the timed steps
-    kern = {}
-    for which, name in enumerate(("phase_a", "phase_b", "em_sweep_and_refits", "labels")):
-        ms, n = ctypes.c_double(), ctypes.c_int32()
-        lib.scape_hip_timing_get(h, which, ctypes.byref(ms), ctypes.byref(n))
-        kern[name] = dict(ms_total=ms.value, launches=n.value)
-    rounds, slab, zel = eng.last_main_counters
-    em_avg_ms = em_ms[0] / args.steps
-    host_ms = dict(eng.last_host_ms)
+    def measure(U, reads, kcap, steps, warmup, index0, base_seed, rerun_leg=True):
+        """One workload shape: U synthetic UTRs x `reads` reads resident in HBM, K = 1..kcap x 10 restarts; `steps` timed
+        passes of the hot path, then one extra sweep with an event pair around every per-round kernel (roofline)."""
+        kw = dict(n_max_apa=kcap, n_min_apa=1)
+        t_prep = time.perf_counter()
+        preps = []
+        for i in range(U):
+            gene, df, _truth = synth_utr(index0 + i, reads, k_cap=kcap, base_seed=base_seed)
+            preps.append(prepare_utr(df, gene_info_str=gene, **kw))
+        plan = eng.plan(preps, [(base_seed + index0 + i) % 2 ** 32 for i in range(U)])
+        t_prep = time.perf_counter() - t_prep
+        t_h2d = time.perf_counter()
+        batch = HipBatch(eng.ctx, preps)            # inputs resident in HBM from here on
+        t_h2d = time.perf_counter() - t_h2d
+        em_ms = [0.0]
 
-    # the same timed region with re_run_mode on (the reference's default): UTRs whose K hits the cap
-    # get a second, larger sweep through the generic state machine
-    rr_steps = max(1, min(args.steps, 2))
-    rr_elapsed, _ = timed(lambda: eng.process(batch, preps, plan, re_run_mode=True), rr_steps)
+        def step():
+            r = eng.process(batch, preps, plan, re_run_mode=False)
+            em_ms[0] += eng.last_main_em_ms
+            return r
 
-    # one extra, untimed step with an event pair around every per-round kernel: average duration of the
-    # dominant kernel (k2_mstep, one launch per EM round) measured live on the launch stream, and the
-    # kernel's own byte tally of that sweep
-    os.environ["SCAPE_HIP_ROUND_TIMING"] = "1"
-    lib.scape_hip_timing_reset(h)
-    batch.build()
-    batch.em_packed(plan["main"])
-    del os.environ["SCAPE_HIP_ROUND_TIMING"]
-    traffic = batch.em_traffic()
-    per = {}
-    for which, name in ((4, "k2_estep"), (5, "k2_mstep")):
-        ms, n = ctypes.c_double(), ctypes.c_int32()
-        lib.scape_hip_timing_get(h, which, ctypes.byref(ms), ctypes.byref(n))
-        per[name] = (ms.value, n.value)
-        kern[name + "_profiled_step"] = dict(ms_total=ms.value, launches=n.value)
-    m_ms, m_n = per["k2_mstep"]
-    m_avg_ms = m_ms / max(m_n, 1)
-    assert traffic["launches"] == m_n, (traffic, m_n)
-    alg_bytes = 8.0 * slab / max(m_n, 1)                # SURVEY.md 8(d) slab term (job-at-a-time), per M-step launch
-    hbm_bytes = (traffic["tensor_bytes"] + traffic["v_bytes_unique"]) / max(m_n, 1)
-    achieved = hbm_bytes / (m_avg_ms * 1e-3) / 1e9
-    tensor_bytes = 8.0 * sum(q.T * len(q.betas) * ((q.N + 15) // 16 * 16) for q in preps)
+        for _ in range(warmup):
+            res = step()
+        lib.scape_hip_timing_reset(h)
+        em_ms[0] = 0.0
+        elapsed, res = timed(step, steps)
 
-    if rank == 0:
+        # kernel timing (HIP events on the library's stream) of the timed steps
+        kern = {}
+        for which, name in enumerate(("phase_a", "phase_b", "em_sweep_and_refits", "labels")):
+            ms, n = ctypes.c_double(), ctypes.c_int32()
+            lib.scape_hip_timing_get(h, which, ctypes.byref(ms), ctypes.byref(n))
+            kern[name] = dict(ms_total=ms.value, launches=n.value)
+        rounds, slab, zel = eng.last_main_counters
+        em_avg_ms = em_ms[0] / steps
+        host_ms = dict(eng.last_host_ms)
+
+        # SURVEY.md 8(d): the same timed region with re_run_mode on (the reference's default): UTRs whose K hits the cap
+        # get a second, larger sweep through the generic state machine
+        rr = None
+        if rerun_leg:
+            rr_steps = max(1, min(steps, 2))
+            rr_elapsed, _ = timed(lambda: eng.process(batch, preps, plan, re_run_mode=True), rr_steps)
+            rr = {"value": world * U * rr_steps / rr_elapsed, "unit": "UTRs/s", "steps": rr_steps,
+                  "ms_per_step": 1e3 * rr_elapsed / rr_steps,
+                  "note": "same resident batch and timed region with the re-run rule of subsample_run "
+                          "(apa_core.py:1023-1030) on"}
+
+        # one extra, untimed step with an event pair around every per-round kernel: average duration of the
+        # dominant kernel (the M-step, one launch per EM round) measured live on the launch stream, and the
+        # kernel's own byte tally of that sweep
+        os.environ["SCAPE_HIP_ROUND_TIMING"] = "1"
+        lib.scape_hip_timing_reset(h)
+        batch.build()
+        batch.em_packed(plan["main"])
+        del os.environ["SCAPE_HIP_ROUND_TIMING"]
+        traffic = batch.em_traffic()
+        per = {}
+        for which, name in ((4, "k2_estep"), (5, "k2_mstep")):
+            ms, n = ctypes.c_double(), ctypes.c_int32()
+            lib.scape_hip_timing_get(h, which, ctypes.byref(ms), ctypes.byref(n))
+            per[name] = (ms.value, n.value)
+            kern[name + "_profiled_step"] = dict(ms_total=ms.value, launches=n.value)
+        m_ms, m_n = per["k2_mstep"]
+        m_avg_ms = m_ms / max(m_n, 1)
+        assert traffic["launches"] == m_n, (traffic, m_n)
+        alg_bytes = 8.0 * slab / max(m_n, 1)                # SURVEY.md 8(d) slab term (job-at-a-time), per M-step launch
+        hbm_bytes = (traffic["tensor_bytes"] + traffic["v_bytes_unique"]) / max(m_n, 1)
+        achieved = hbm_bytes / (m_avg_ms * 1e-3) / 1e9
+        tensor_bytes = 8.0 * sum(q.T * len(q.betas) * ((q.N + 15) // 16 * 16) for q in preps)
         N = np.array([q.N for q in preps])
         T = np.array([q.T for q in preps])
+        roofline = {"bound": "hbm", "kernel": "k3_mstep (tile-stationary f64-MFMA M-step on LDS-DMA rings, one launch per EM round)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": hbm_bytes,
+                    "traffic_source": "tallied by the kernel itself (scape_hip_em_traffic): tensor-tile bytes "
+                                      "streamed + each job's v vector once, per launch; the rocprofv3 FETCH_SIZE "
+                                      "pass of the same command is in profiles/ (README: how they compare)",
+                    "traffic_tensor_bytes": traffic["tensor_bytes"] / max(m_n, 1),
+                    "traffic_v_bytes_unique": traffic["v_bytes_unique"] / max(m_n, 1),
+                    "v_bytes_requested_incl_l2_hits": traffic["v_bytes_requested"] / max(m_n, 1),
+                    "launch_ms": m_avg_ms, "launches_per_sweep": m_n,
+                    "algorithmic_bytes_per_launch": alg_bytes, "reuse_factor": alg_bytes / max(hbm_bytes, 1.0),
+                    "tensor_bytes_streamed_once": tensor_bytes,
+                    "note": "achieved = traffic / launch_ms (HIP events on the launch stream).  "
+                            "algorithmic_bytes_per_launch = SURVEY.md 8(d)'s 8*N*B*|window| summed over jobs "
+                            "(what a job-at-a-time M-step reads); the kernel streams each live tensor tile once "
+                            "per round for all jobs that need it: reuse_factor = algorithmic / traffic",
+                    "em_sweep_ms": em_avg_ms, "em_rounds_per_sweep": int(rounds),
+                    "mfma_f64_tflops": 2.0 * slab / (m_ms * 1e-3) / 1e12}
+        return dict(preps=preps, plan=plan, res=res, batch=batch, elapsed=elapsed, kern=kern, host_ms=host_ms, rr=rr,
+                    roofline=roofline, t_prep=t_prep, t_h2d=t_h2d, n_frag_mean=float(N.mean()), n_frag_max=int(N.max()),
+                    n_theta_mean=float(T.mean()), value=world * U * steps / elapsed, ms_per_step=1e3 * elapsed / steps)
+
+    U = args.utrs
+    m = measure(U, args.reads, args.kcap, args.steps, args.warmup, rank * U, args.base_seed)
+    preps, plan, res, batch = m["preps"], m["plan"], m["res"], m["batch"]
+
+    if rank == 0:
         out = {
             "metric": "UTR regions/sec (infer_pa EM to convergence), 50k UTRs x 2k reads synthetic",
-            "value": world * U * args.steps / elapsed, "unit": "UTRs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "value": m["value"], "unit": "UTRs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"50k-UTR synthetic stream x {args.reads} reads, K=1..{args.kcap} x 10 restarts; "
                                    f"step = one resident batch of {U} UTRs per GPU",
                        "utrs_per_gpu_per_step": U, "reads_per_utr": args.reads, "k_cap": args.kcap,
-                       "em_jobs_per_step": int(len(plan["main"])), "n_frag_mean": float(N.mean()),
-                       "n_frag_max": int(N.max()), "n_theta_mean": float(T.mean()), "re_run_mode": False,
+                       "em_jobs_per_step": int(len(plan["main"])), "n_frag_mean": m["n_frag_mean"],
+                       "n_frag_max": m["n_frag_max"], "n_theta_mean": m["n_theta_mean"], "re_run_mode": False,
                        "rng_mode": "per_utr", "parallelism": f"utr-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k2_mstep (tile-stationary f64-MFMA M-step, one launch per EM round)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": hbm_bytes,
-                         "traffic_source": "tallied by the kernel itself (scape_hip_em_traffic): tensor-tile bytes "
-                                           "streamed + each job's v vector once, per launch; the rocprofv3 FETCH_SIZE "
-                                           "pass of the same command is in profiles/ (README: how they compare)",
-                         "traffic_tensor_bytes": traffic["tensor_bytes"] / max(m_n, 1),
-                         "traffic_v_bytes_unique": traffic["v_bytes_unique"] / max(m_n, 1),
-                         "v_bytes_requested_incl_l2_hits": traffic["v_bytes_requested"] / max(m_n, 1),
-                         "launch_ms": m_avg_ms, "launches_per_sweep": m_n,
-                         "algorithmic_bytes_per_launch": alg_bytes, "reuse_factor": alg_bytes / max(hbm_bytes, 1.0),
-                         "tensor_bytes_streamed_once": tensor_bytes,
-                         "note": "achieved = traffic / launch_ms (HIP events on the launch stream).  "
-                                 "algorithmic_bytes_per_launch = SURVEY.md 8(d)'s 8*N*B*|window| summed over jobs "
-                                 "(what a job-at-a-time M-step reads); the kernel streams each live tensor tile once "
-                                 "per round for all jobs that need it: reuse_factor = algorithmic / traffic",
-                         "em_sweep_ms": em_avg_ms, "em_rounds_per_sweep": int(rounds),
-                         "mfma_f64_tflops": 2.0 * slab / (m_ms * 1e-3) / 1e12},
-            "kernels_ms": kern,
-            "re_run_mode_true": {"value": world * U * rr_steps / rr_elapsed, "unit": "UTRs/s", "steps": rr_steps,
-                                 "ms_per_step": 1e3 * rr_elapsed / rr_steps,
-                                 "note": "same resident batch and timed region with the re-run rule of subsample_run "
-                                         "(apa_core.py:1023-1030) on"},
-            "host": {"prep_s": t_prep, "h2d_s": t_h2d, "process_ms": host_ms, **host_info()},
+            "roofline": m["roofline"],
+            "kernels_ms": m["kern"],
+            "re_run_mode_true": m["rr"],
+            "host": {"prep_s": m["t_prep"], "h2d_s": m["t_h2d"], "process_ms": m["host_ms"], **host_info()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = min(16, os.cpu_count() or 1)
+            hi = host_info()
+            cores = hi["physical_cores"]
+            if hi["cgroup_cpu_limit"]:
+                cores = max(1, min(cores, int(hi["cgroup_cpu_limit"] + 0.5)))
             cb, outs = cpu_baseline(preps, plan, args.cpu_seconds, cores)
             out["cpu_baseline"] = cb
             same = parity_count(preps, plan, res, outs)
             out["cpu_baseline"]["parity_sample"] = f"{same}/{len(outs)} sampled UTRs: GPU pA calls identical to the CPU port"
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / cb["value"]
-            out["cpu_baseline"].update(host_info())
+            out["cpu_baseline"]["gpu_over_cpu_single_thread"] = out["value"] / cb["single_thread_value"]
+            out["cpu_baseline"].update(hi)
     batch.free()
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        # The other single-GPU BASELINE shapes, two steps each through the same timed region: config #2 (1k x 500 reads,
+        # K <= 5), and - one GPU's share of - config #4 (10k reads, K <= 10) and config #5 (5k reads, K = 1..12)
+        oc = []
+        for name, (U2, reads2, kcap2) in (("config #2: 500 reads, K<=5", (2048, 500, 5)),
+                                          ("config #4 shape: 10,000 reads, K<=10", (256, 10000, 10)),
+                                          ("config #5 shape: 5,000 reads, K=1..12", (256, 5000, 12))):
+            m2 = measure(U2, reads2, kcap2, 2, 1, 4 * 10 ** 6, args.base_seed, rerun_leg=False)
+            e = {"workload": f"{name}; step = one resident batch of {U2} UTRs", "value": m2["value"], "unit": "UTRs/s",
+                 "steps": 2, "ms_per_step": m2["ms_per_step"], "n_frag_mean": m2["n_frag_mean"],
+                 "em_jobs_per_step": int(len(m2["plan"]["main"])),
+                 "roofline": {k: m2["roofline"][k] for k in ("achieved", "frac", "traffic", "launch_ms", "launches_per_sweep",
+                                                            "em_sweep_ms", "mfma_f64_tflops", "reuse_factor")}}
+            if not args.no_cpu_baseline:
+                hi = host_info()
+                cores = hi["physical_cores"]
+                if hi["cgroup_cpu_limit"]:
+                    cores = max(1, min(cores, int(hi["cgroup_cpu_limit"] + 0.5)))
+                cb2, outs2 = cpu_baseline(m2["preps"], m2["plan"], args.cpu_seconds / 4, cores, max_utrs=cores)
+                same2 = parity_count(m2["preps"], m2["plan"], m2["res"], outs2)
+                e["parity_sample"] = f"{same2}/{len(outs2)} sampled UTRs: GPU pA calls identical to the CPU port"
+                e["cpu_port"] = {k: cb2[k] for k in ("value", "cores", "single_thread_value", "sample")}
+            m2["batch"].free()
+            oc.append(e)
+        out["other_configs"] = oc
     if rank == 0:
         if world == 1 and pool is not None:
             out["single_chunk_reference"] = single_chunk_reference(args, dev)
+            out["cli_single_chunk"] = cli_single_chunk(args)
             out["end_to_end"] = end_to_end(args, pool, dev)
     if dist is not None:
         dist.barrier()                           # every rank has released its batch

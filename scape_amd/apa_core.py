@@ -90,9 +90,10 @@ def _dump_toml(d, fh):
     fh.write("".join(lines).encode())
 
 
-def read_input_chunk(path):
+def read_input_chunk(path, frames="pandas"):
     """Stream of (gene_info_str, DataFrame) tuples (input_processor.py:223-259).  Uses the
-    non-executing reader; SCAPE_TRUST_PICKLE=1 switches to pickle.load like the reference."""
+    non-executing reader; SCAPE_TRUST_PICKLE=1 switches to pickle.load like the reference.
+    frames="columns": the frames come back as plain column mappings (safe_pickle.Columns), no pandas import."""
     if os.environ.get("SCAPE_TRUST_PICKLE") == "1":
         with open(path, "rb") as fh:
             while True:
@@ -101,7 +102,7 @@ def read_input_chunk(path):
                 except EOFError:
                     return
     else:
-        yield from safe_pickle.iter_pickles(path)
+        yield from safe_pickle.iter_pickles(path, frames=frames)
 
 
 def load_preps(pkl_input_file, kwargs):
@@ -118,18 +119,44 @@ def load_preps(pkl_input_file, kwargs):
     if is_current(bp, pkl_input_file):
         return [prepare_binned(b, gene_info_str=g, pre_para=pre_para, **kwargs) for g, b, _j in read_binned(bp)]
     return [prepare_utr(df, gene_info_str=gene, pre_para=pre_para, **kwargs)
-            for gene, df in read_input_chunk(pkl_input_file)]
+            for gene, df in read_input_chunk(pkl_input_file, frames="columns")]
 
 
 def infer(pickle_input_file, pickle_output_file, **kwargs):
-    """Reference ``infer`` (apa_core.py:1104-1137): one Parameters per input tuple, same order."""
+    """Reference ``infer`` (apa_core.py:1104-1137): one Parameters per input tuple, same order.
+
+    The HIP context and library handle come up on a side thread (the runtime calls release the GIL) while this thread
+    reads and prepares the chunk.  SCAPE_TIMING_JSON=<path>: the stage seconds of this call are written there
+    (bench.py's `cli_single_chunk` leg)."""
+    import threading
     print(f"start inferring APA events from input pickle file = {pickle_input_file}. "
           f"Output file = {pickle_output_file}")
     start_t = timer()
-    preps = load_preps(pickle_input_file, kwargs)
-    engine = Engine(device=kwargs.get("device"))
+    box = {}
+
+    def bring_up():
+        t0 = timer()
+        try:
+            box["engine"] = Engine(device=kwargs.get("device"))
+        except BaseException as e:                # re-raised on the calling thread
+            box["error"] = e
+        box["context_s"] = timer() - t0
+    th = threading.Thread(target=bring_up, name="scape-hip-context")
+    th.start()
+    t0 = timer()
+    try:
+        preps = load_preps(pickle_input_file, kwargs)
+    finally:
+        th.join()
+    t_prep = timer() - t0
+    if "error" in box:
+        raise box["error"]
+    engine = box["engine"]
+    t0 = timer()
     results = engine.run(preps, rng_mode=kwargs.get("rng_mode", "reference"), seed=int(kwargs.get("seed", 1)),
                          re_run_mode=bool(kwargs.get("re_run_mode", True)))
+    t_fit = timer() - t0
+    t0 = timer()
     res_lst = [to_parameters(r) for r in results]
     for res in res_lst:
         print(res)
@@ -138,6 +165,15 @@ def infer(pickle_input_file, pickle_output_file, **kwargs):
         for res in res_lst:
             print(f"save result of {res.gene_info_str}")
             pickle.dump(res, fh)
+    t_out = timer() - t0
+    tj = os.environ.get("SCAPE_TIMING_JSON")
+    if tj:
+        import json
+        import sys
+        t_imp = getattr(sys.modules.get("scape"), "_IMPORT_S", None)
+        with open(tj, "w") as fh:
+            json.dump({"imports_s": t_imp or 0.0, "read_prepare_s": t_prep, "hip_context_s_overlapped_with_read_prepare": box["context_s"],
+                       "fit_s": t_fit, "print_pickle_s": t_out, "utrs": len(res_lst)}, fh)
     return res_lst
 
 

@@ -494,3 +494,32 @@ def test_prediction_pass_failure_is_not_a_stream_failure():
         assert all(sw.pred is None for sw in sweeps)
         assert eng.last_main_em_ms == 12.5 and eng.last_main_counters == (1, 2, 3)
         assert not hasattr(eng, "last_host_ms")
+
+
+def test_find_peaks_equals_scipy():
+    """scape_amd.host.find_peaks restates scipy.signal.find_peaks(x, distance=d) (apa_core.py:784) so that the CLI
+    does not import scipy.signal; it must return exactly scipy's peaks - also with plateaus, ties between peak
+    heights and peaks closer than the distance."""
+    from scipy.signal import find_peaks as sp
+    from scape_amd.host import find_peaks
+    rs = np.random.RandomState(5)
+    cases = []
+    for trial in range(300):
+        n = int(rs.randint(3, 400))
+        kind = trial % 4
+        if kind == 0:
+            x = rs.random_sample(n)
+        elif kind == 1:
+            x = rs.randint(0, 4, n).astype(float)                     # plateaus and equal heights everywhere
+        elif kind == 2:
+            x = np.convolve(rs.poisson(2.0, n).astype(float), np.ones(7) / 7, mode="same")
+        else:
+            x = np.repeat(rs.randint(0, 6, n // 3 + 1), 3)[:n].astype(float)
+        cases.append(x)
+    cases += [np.zeros(5), np.array([0., 1, 0]), np.array([1., 1, 1]), np.array([0., 2, 2, 0, 2, 2, 2, 0]), np.arange(10.0)]
+    for x in cases:
+        for d in (1, 2, 3.5, 10, 100):
+            want = sp(x, distance=d)[0]
+            got = find_peaks(x, d)[0]
+            assert np.array_equal(got, want), (x.tolist(), d, got, want)
+    assert len(find_peaks(np.array([1.0, 2.0]), 5)[0]) == 0
