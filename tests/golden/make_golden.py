@@ -28,7 +28,7 @@ reference never travels: only the ``.npz`` files do.
    of the reference's own ``proc_junction_{pos,neg}_pa`` run here on randomly generated genes
    (several UTR records per gene, junction reads that trigger merges, tied positions, empty sites).
 
-Usage: python tests/golden/make_golden.py [fixtures|traces|synth|fixed|highk|merge|all] [names...]
+Usage: python tests/golden/make_golden.py [fixtures|traces|synth|fixed|highk|merge|mergechain|all] [names...]
 """
 from __future__ import annotations
 
@@ -562,6 +562,60 @@ def write_merge_trace(n_genes=150, seed=20250226):
     print("wrote", path, os.path.getsize(path), "cases", n_case, "skipped (reference did not finish)", skipped)
 
 
+def write_merge_chain():
+    """fixture_merge_chain.npz: the REFERENCE's own merge_pa (junction_handler.py:44-147, both modes) run on the directory
+    of tests/merge_chain_dir.py, with pkl_output/*.res.pkl holding the oracle's fits of its records from the seeds
+    `infer_pa_all` uses in rng_mode per_utr.  The GPU chain test must reproduce every field of res.gene.pkl / res.utr.pkl."""
+    import pickle
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import merge_chain_dir as mc
+    from oracle import scape_oracle as so
+    load_reference()
+    import importlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        jh = importlib.import_module("scape.junction_handler")
+    RefPara = sys.modules["scape.apa_core"].Parameters
+    root = tempfile.mkdtemp(prefix="merge_chain_")
+    try:
+        recs = mc.write_inputs(root)
+        d = {"n_rec": np.array(len(recs))}
+        outs = [open(os.path.join(root, "pkl_output", mc.stem(fi) + ".res.pkl"), "wb") for fi in range(mc.N_FILES)]
+        for ri, (fi, j, g, df) in enumerate(recs):
+            np.random.seed(mc.SEED + j)
+            res, model = so.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, re_run_mode=True, **mc.KW)
+            p = RefPara(title="Final Result", alpha_arr=np.asarray(res.alpha_arr), beta_arr=np.asarray(res.beta_arr),
+                        ws=np.asarray(res.ws), L=int(model.L), cb_id_arr=df["cb_id"].to_numpy(), readID_arr=df["read_id"].to_numpy())
+            p.bic, p.lb_arr, p.label_arr, p.gene_info_str = res.bic, res.lb_arr, np.asarray(res.label_arr), g
+            pickle.dump(p, outs[fi])
+            _put_para(d, f"fit{ri}_", p, with_ws=True)
+        for fh in outs:
+            fh.close()
+        for mode, fn in ((True, "res.gene.pkl"), (False, "res.utr.pkl")):
+            with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    jh._merge_pa(root, mode)
+            got = []
+            with open(os.path.join(root, fn), "rb") as fh:          # (written by the line above, in this process)
+                while True:
+                    try:
+                        got.append(pickle.load(fh))
+                    except EOFError:
+                        break
+            tag = "gene" if mode else "utr"
+            d[f"{tag}_n"] = np.array(len(got))
+            for k, p in enumerate(got):
+                _put_para(d, f"{tag}{k}_", p, with_ws=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    path = os.path.join(HERE, "fixture_merge_chain.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path), "records", len(recs), "gene groups", int(d["gene_n"]), "utr groups", int(d["utr_n"]))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     names = sys.argv[2:] or list(FIXTURE_FILES)
@@ -576,5 +630,7 @@ if __name__ == "__main__":
     if what in ("merge", "all"):
         write_merge_fixtures()
         write_merge_trace()
+    if what in ("mergechain", "all"):
+        write_merge_chain()
     if what in ("traces", "all"):
         write_traces(names)

@@ -923,3 +923,32 @@ def test_deep_pileup_shapes_vs_oracle(oracle, reads, kcap, n):
         assert para.K == want.K and np.array_equal(para.alpha_arr, want.alpha_arr)
         assert np.array_equal(para.beta_arr, want.beta_arr) and np.array_equal(para.label_arr, want.label_arr)
         assert np.allclose(para.ws, want.ws, rtol=1e-4, atol=1e-9)
+
+
+def test_infer_pa_all_then_merge_pa_vs_reference(tmp_path):
+    """SURVEY.md 8(f) rank 3 end to end on the GPU: `infer_pa_all` (this build, GPU) writes pkl_output/*.res.pkl for the
+    synthetic chunk directory of tests/merge_chain_dir.py, `merge_pa` (this build) merges it; the expectation is the
+    REFERENCE's own merge_pa (junction_handler.py:44-147) run on the same directory with the oracle's fits
+    (tests/golden/fixture_merge_chain.npz).  Every per-UTR fit must equal the oracle's (K, alpha, beta, all labels, the
+    read / cell ids) and both merged outputs must equal the reference's in every field."""
+    import pickle
+    import merge_chain_dir as mc
+    from conftest import load_npz
+    from test_merge_pa import _chain_check
+    from scape_amd.apa_core import infer_all
+    f = load_npz("fixture_merge_chain.npz")
+    recs = mc.write_inputs(str(tmp_path))
+    infer_all(str(tmp_path), gpus=1, rng_mode="per_utr", seed=mc.SEED, re_run_mode=True, **mc.KW)
+    ri = 0
+    for fi in range(mc.N_FILES):
+        with open(tmp_path / "pkl_output" / (mc.stem(fi) + ".res.pkl"), "rb") as fh:
+            for _ in range(mc.PER_FILE):
+                p, pre = pickle.load(fh), f"fit{ri}_"
+                assert p.gene_info_str == recs[ri][2] == str(f[pre + "gene_info_str"])
+                assert p.K == int(f[pre + "K"]) and p.L == int(f[pre + "L"])
+                for k in ("alpha_arr", "beta_arr", "label_arr", "cb_id_arr", "readID_arr"):
+                    assert np.array_equal(getattr(p, k), f[pre + k]), (p.gene_info_str, k)
+                assert np.allclose(p.ws, f[pre + "ws"], rtol=1e-9, atol=1e-13)
+                ri += 1
+    assert ri == len(recs)
+    _chain_check(tmp_path, f)

@@ -178,3 +178,43 @@ def test_parallel_merge_over_chunk_files_equals_serial(tmp_path):
         n1 = _merge_pa(str(out), mode, workers=2)
         assert n0 == n1 > 0 and open(out / name, "rb").read() == serial
         assert not [p for p in os.listdir(out) if ".part" in p]
+
+
+def _chain_check(root, f):
+    """res.gene.pkl / res.utr.pkl of `root` (written by this build's merge_pa) against the reference's own merge_pa run
+    on the same directory content (tests/golden/fixture_merge_chain.npz, generator make_golden.py mergechain)."""
+    from scape_amd.junction_handler import _merge_pa
+    for mode, fn, tag in ((True, "res.gene.pkl", "gene"), (False, "res.utr.pkl", "utr")):
+        _merge_pa(str(root), mode, workers=0)
+        got = []
+        with open(os.path.join(root, fn), "rb") as fh:
+            while True:
+                try:
+                    got.append(pickle.load(fh))
+                except EOFError:
+                    break
+        want = {str(f[f"{tag}{k}_gene_info_str"]): f"{tag}{k}_" for k in range(int(f[f"{tag}_n"]))}
+        assert len(got) == len(want) and {p.gene_info_str for p in got} == set(want)
+        for para in got:
+            _same(para, f, want[para.gene_info_str])
+
+
+def test_merge_chain_directory_vs_reference_merge(tmp_path):
+    """The infer_pa -> merge_pa chain directory (tests/merge_chain_dir.py) with the ORACLE's fits as pkl_output: this
+    build's merge_pa must write what the reference's merge_pa wrote for it (both modes, every field).  The -m gpu
+    twin (test_gpu_parity.py::test_infer_pa_all_then_merge_pa_vs_reference) replaces the oracle's fits by the GPU's."""
+    import merge_chain_dir as mc
+    from scape_amd.apa_core import Parameters
+    f = load_npz("fixture_merge_chain.npz")
+    recs = mc.write_inputs(str(tmp_path))
+    outs = [open(tmp_path / "pkl_output" / (mc.stem(fi) + ".res.pkl"), "wb") for fi in range(mc.N_FILES)]
+    for ri, (fi, _j, g, df) in enumerate(recs):
+        pre = f"fit{ri}_"
+        assert str(f[pre + "gene_info_str"]) == g
+        p = Parameters(title="Final Result", alpha_arr=f[pre + "alpha_arr"], beta_arr=f[pre + "beta_arr"], ws=f[pre + "ws"],
+                       L=int(f[pre + "L"]), cb_id_arr=f[pre + "cb_id_arr"], readID_arr=f[pre + "readID_arr"])
+        p.label_arr, p.gene_info_str = f[pre + "label_arr"], g
+        pickle.dump(p, outs[fi])
+    for fh in outs:
+        fh.close()
+    _chain_check(tmp_path, f)
