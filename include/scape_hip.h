@@ -30,11 +30,11 @@
 extern "C" {
 #endif
 
-#define SCAPE_HIP_ABI_VERSION 3
+#define SCAPE_HIP_ABI_VERSION 4
 #define SCAPE_SENT (-3.4028234663852886e38)
-#define SCAPE_MAX_BETA 64    /* max len(predef_beta_arr) */
+#define SCAPE_MAX_BETA 160   /* max len(predef_beta_arr): beta_step >= 0.44 at the default max_beta = 70 (ABI 3: 64) */
 #define SCAPE_MAX_S 64       /* max len(s_dis_arr)       */
-#define SCAPE_MAX_K 31       /* max number of pA components per model (K+1 <= 32) */
+#define SCAPE_MAX_K 63       /* max number of pA components per model (K+1 <= 64; ABI 3: 31) */
 #define SCAPE_MAX_JOBS_PER_UTR 1024  /* max non-fixed jobs on one UTR in one scape_hip_batch_em call */
 
 typedef struct scape_hip_ctx scape_hip_ctx;

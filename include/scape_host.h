@@ -24,8 +24,8 @@
 extern "C" {
 #endif
 
-#define SCAPE_HOST_ABI_VERSION 1
-#define SCAPE_HOST_MAX_K 32
+#define SCAPE_HOST_ABI_VERSION 2
+#define SCAPE_HOST_MAX_K 64
 
 int scape_host_abi_version(void);
 

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscape_host.so")
-MAX_K = 32
+MAX_K = 64
 STATE_WORDS = 625
 
 c_d, c_i, c_i32, c_u32 = ctypes.c_double, ctypes.c_int, ctypes.c_int32, ctypes.c_uint32
@@ -74,7 +74,7 @@ def load_library():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.scape_host_abi_version() != 1:
+        if lib.scape_host_abi_version() != 2:
             raise RuntimeError("libscape_host.so ABI version mismatch")
         _lib = lib
     return _lib

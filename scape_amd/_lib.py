@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 SENT = float(np.finfo("f").min)   # reference taichi_core.py:8 / apa_core.py:428
-MAX_BETA, MAX_S, MAX_K = 64, 64, 31
+MAX_BETA, MAX_S, MAX_K = 160, 64, 63
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCAPE_HIP_LIB") or os.path.join(_HERE, "libscape_hip.so")   # override: A/B builds only
 
@@ -78,7 +78,7 @@ def load_library():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.scape_hip_abi_version() != 3:
+        if lib.scape_hip_abi_version() != 4:
             raise ScapeHipError("libscape_hip.so ABI version mismatch")
         _lib = lib
     return _lib

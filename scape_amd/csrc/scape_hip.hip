@@ -629,6 +629,7 @@ __global__ __launch_bounds__(256, 5) void k_phase_b(const UtrDesc *__restrict__ 
     }
 }
 
+#ifdef SCAPE_HIP_TOOLS   // the round-1 job-at-a-time EM kernel: A/B builds only (-DSCAPE_HIP_TOOLS), not in the product library
 // ------------------------------------------------------------------------------------------
 // EM: one workgroup per job (UTR, K, restart).  apa_core.py:714-779.
 // Column c of log_zmat is never stored: it is snap_lw[c] + M[snap_ia[c]][snap_ib[c]][:] where
@@ -905,6 +906,8 @@ __global__ __launch_bounds__(EM_THREADS) void k_em(
         atomicAdd(&counters[2], (unsigned long long)n_lb * (unsigned long long)N * (unsigned long long)C);
     }
 }
+
+#endif
 
 #include "em_lockstep.inc"
 #include "mstep_ring.inc"
@@ -1326,7 +1329,8 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         else if (kmax + 1 <= 12) LAUNCH_ALL(12);
         else if (kmax + 1 <= 16) LAUNCH_ALL(16);
         else if (kmax + 1 <= 24) LAUNCH_ALL(24);
-        else LAUNCH_ALL(32);
+        else if (kmax + 1 <= 32) LAUNCH_ALL(32);
+        else LAUNCH_ALL(64);
 #undef LAUNCH_ALL
         HIPCHK(hipGetLastError());
         if (fine && ev_end(c, 4)) return 1;
@@ -1334,6 +1338,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         return 0;
     }
     unsigned long long executed_prev = 0;
+    const int probe_mask = (n_jobs >= 8192) ? 7 : 3;
     int rc = 0;
     for (int r = 0; r <= nround && !rc; ++r) {
         for (int g = 0; g < n_grp && !rc; ++g) {
@@ -1362,7 +1367,8 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
             else if (kmax + 1 <= 12) LAUNCH_E(k2_estep, 12, 64);
             else if (kmax + 1 <= 16) LAUNCH_E(k2_estep, 16, 64);
             else if (kmax + 1 <= 24) LAUNCH_E(k2_estep, 24, 64);
-            else LAUNCH_E(k2_estep, 32, 64);
+            else if (kmax + 1 <= 32) LAUNCH_E(k2_estep, 32, 64);
+            else LAUNCH_E(k2_estep, 64, 64);      // K up to 63: the column arrays live in scratch there - slow, and rare (a re-run loop that keeps growing, apa_core.py:1023-1030)
 #undef LAUNCH_E
             HIPCHK(hipGetLastError());
             if (fine && ev_end(c, 4)) return 1;
@@ -1386,8 +1392,10 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                 if (fine && ev_end(c, 5)) return 1;
             }
         }
-        if (r < nround && (r & 3) == 3) {
-            // early exit: no job executed a round since the last probe -> every job has been finalised
+        // early exit: no job executed a round since the last probe -> every job has been finalised.  The probe waits for
+        // the stream (a bubble of a few tens of microseconds): every 4 rounds for small calls, whose jobs all finish
+        // early and whose rounds are short, every 8 for wave-sized ones, which run to the last round anyway
+        if (r < nround && (r & probe_mask) == probe_mask) {
             unsigned long long executed = 0, shard[64];
             if (split) HIPCHK(hipStreamSynchronize(c->stream2));
             HIPCHK(hipMemcpyAsync(shard, c->d_counters.as<unsigned long long>() + CNT_EXEC, sizeof(shard),
@@ -1809,12 +1817,13 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipMemsetAsync(c->d_counters.p, 0, N_COUNTERS * sizeof(unsigned long long), c->stream));
     HIPCHK(hipMemsetAsync(c->j_lb.p, 0, nj * nround * 8, c->stream));
     c->h_traffic[3] = 0;
-    const char *mode = getenv("SCAPE_HIP_EM");
-    const bool use_v1 = mode && strcmp(mode, "v1") == 0;
     if (ev_begin(c, 2)) return 1;
-    if (use_v1) {
+#ifdef SCAPE_HIP_TOOLS
+    const char *mode = getenv("SCAPE_HIP_EM");
+    if (mode && strcmp(mode, "v1") == 0) {
         const size_t lds = (size_t)c->Np_max * sizeof(double);
         if (lds > 150 * 1024) return fail("n_frag too large for the LDS-resident v1 EM kernel (use the default lock-step EM)");
+        if (kmax + 1 > 32) return fail("v1 EM kernel: K <= 31");
 #define LAUNCH_EM(CM)                                                                                         \
     hipLaunchKernelGGL(k_em<CM>, dim3(n_jobs), dim3(EM_THREADS), lds, c->stream, c->d_desc.as<UtrDesc>(),     \
                        c->prm, c->d_cnt.as<double>(), c->d_M.as<double>(), kmax, c->j_utr.as<int32_t>(),      \
@@ -1828,9 +1837,9 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
         else LAUNCH_EM(32);
 #undef LAUNCH_EM
         HIPCHK(hipGetLastError());
-    } else {
-        if (em_lockstep(c, n_jobs, kmax, job_utr, job_fixed)) return 1;
-    }
+    } else
+#endif
+    if (em_lockstep(c, n_jobs, kmax, job_utr, job_fixed)) return 1;
     if (ev_end(c, 2)) return 1;
     HIPCHK(hipMemcpyAsync(alpha_idx_out, c->j_ao.p, nj * kmax * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(beta_idx_out, c->j_bo.p, nj * kmax * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1915,7 +1924,8 @@ int scape_hip_batch_labels(scape_hip_ctx *c, int32_t n_sel, int32_t kmax, const 
                        c->l_labels.as<int32_t>())
     if (kmax + 1 <= 8) LAUNCH_LAB(8);
     else if (kmax + 1 <= 16) LAUNCH_LAB(16);
-    else LAUNCH_LAB(32);
+    else if (kmax + 1 <= 32) LAUNCH_LAB(32);
+    else LAUNCH_LAB(64);
 #undef LAUNCH_LAB
     HIPCHK(hipGetLastError());
     if (ev_end(c, 3)) return 1;

@@ -89,20 +89,32 @@ def infer_chunk_sharded(pkl_input_file, pickle_output_file, device=None, **kwarg
     from .engine import Engine
     from .host import prepare_utr
     rank, local, world = env_rank_world()
-    utrs = list(read_input_chunk(pkl_input_file))
-    preps = [prepare_utr(df, gene_info_str=g, **kwargs) for g, df in utrs]
-    costs = [utr_cost(q.N, q.T, len(q.betas), q.p["n_max_apa"], q.p["n_min_apa"]) for q in preps]
+    utrs = list(read_input_chunk(pkl_input_file, frames="columns"))
+    # The shards are cut BEFORE binning, from what the raw columns tell at a glance (reads ~ bins, the read span ~ the
+    # theta grid), so that a rank bins and prepares only its own UTRs - preparing all of them on every rank was host
+    # work x world size.  Every rank computes the same estimate, hence the same partition.
+    from .host import model_params
+    p0 = model_params(kwargs)
+    n_beta = max(1, int(round(p0["max_beta"] / p0["beta_step"])) - 1)
+
+    def estimate(df):
+        x, l = np.asarray(df["x"]), np.asarray(df["l"])
+        L = max(2000, int(x.max()) + int(l.max()) + 50, int(kwargs.get("utr_length", -1) or -1))
+        T = max(1, (L - int(l.min())) // max(1, int(p0["theta_step"])))
+        return utr_cost(len(x), T, n_beta, p0["n_max_apa"], p0["n_min_apa"])
+    costs = [estimate(df) for _g, df in utrs]
     seed = int(kwargs.get("seed", 1))
     eng = Engine(device=local if device is None else device)
 
-    def run_fn(idx_preps):
+    def run_fn(idx_utrs):
         # per-UTR seed follows the global index, so results do not depend on the sharding
-        res = eng.run([q for _gi, q in idx_preps], rng_mode="per_utr",
-                      seeds=[(seed + gi) % (2 ** 32) for gi, _q in idx_preps],
+        preps = [prepare_utr(df, gene_info_str=g, **kwargs) for _gi, (g, df) in idx_utrs]
+        res = eng.run(preps, rng_mode="per_utr",
+                      seeds=[(seed + gi) % (2 ** 32) for gi, _u in idx_utrs],
                       re_run_mode=bool(kwargs.get("re_run_mode", True)))
         return [to_parameters(r) for r in res]
 
-    res = run_sharded(list(enumerate(preps)), costs, run_fn, rank=rank, world=world)
+    res = run_sharded(list(enumerate(utrs)), costs, run_fn, rank=rank, world=world)
     if rank == 0:
         with open(pickle_output_file, "wb") as fh:
             for para in res:

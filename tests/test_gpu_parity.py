@@ -952,3 +952,70 @@ def test_infer_pa_all_then_merge_pa_vs_reference(tmp_path):
                 ri += 1
     assert ri == len(recs)
     _chain_check(tmp_path, f)
+
+
+def _many_sites_utr(n_sites=34, reads=3000, seed=5, gap=140, beta=8.0):
+    """A UTR with more true pA sites than the old K <= 31 limit of the kernels (inputs only)."""
+    rng = np.random.default_rng(seed)
+    alphas = 400 + gap * np.arange(n_sites)
+    comp = rng.integers(0, n_sites, reads)
+    theta = rng.normal(alphas[comp], beta)
+    s = rng.choice(np.arange(20, 150, 10), size=reads)
+    x = np.clip(np.rint(rng.normal(theta + s - 300, 50)), 0, np.maximum(theta - 31, 0))
+    room = np.maximum(theta - x, 31)
+    l = np.clip(np.floor(31 + rng.random(reads) * (np.minimum(132, room) - 31 + 1)), 31, 132)
+    pa = np.full(reads, np.nan)
+    has = rng.random(reads) < 0.3
+    pa[has] = np.rint(theta[has])
+    return pd.DataFrame({"x": x.astype(np.int64), "l": l.astype(np.int64), "r": np.full(reads, np.nan), "pa": pa,
+                         "cb_id": np.arange(reads), "read_id": np.arange(reads)})
+
+
+def test_rerun_loop_beyond_31_components_vs_oracle(oracle):
+    """The reference's re-run loop has no K cap (apa_core.py:1023-1030: n_max_apa += 2 while K == n_max_apa).  A UTR
+    with 34 true sites, n_max_apa = n_min_apa = 31 and min_ws = 0 (nothing pruned) ends its first sweep at K = 31 = n_max
+    and re-runs with K = 33, 32, 31 - jobs beyond the 32-column kernels (ABI 3 stopped there with a warning).  Every
+    em_algo call of both sweeps and the final Parameters against the oracle."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    df = _many_sites_utr()
+    kw = dict(n_max_apa=31, n_min_apa=31, min_ws=0.0)
+    prep = prepare_utr(df, gene_info_str="syn:K33:1:1-5500:+", **kw)
+    eng = Engine(device=0)
+    res = eng.run([prep], rng_mode="per_utr", seed=3, re_run_mode=True, keep_trace=True)[0]
+    np.random.seed(3)
+    want, model = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, re_run_mode=True, **kw)
+    assert model.n_max_apa >= 33 and max(c["K"] for c in model.calls) >= 33          # the loop did go beyond 31
+    assert len(eng.traces[0]) == len(model.calls)
+    q = res.prep
+    for ft, rc in zip(eng.traces[0], model.calls):
+        assert ft.K == rc["K"]
+        assert np.array_equal(q.theta[ft.a_idx], rc["a1"]) and np.array_equal(q.betas[ft.b_idx], rc["b1"]), rc["K"]
+        assert len(ft.lb) == len(rc["lb"]) and np.allclose(ft.ws, rc["w1"], rtol=1e-6, atol=1e-10)
+    para = to_parameters(res)
+    assert para.K == want.K and np.array_equal(para.alpha_arr, want.alpha_arr) and np.array_equal(para.beta_arr, want.beta_arr)
+    assert np.array_equal(para.label_arr, want.label_arr)
+    assert np.allclose(para.ws, want.ws, rtol=1e-6, atol=1e-10) and para.bic == pytest.approx(want.bic, rel=1e-9)
+
+
+def test_beta_step_one_vs_oracle(oracle):
+    """beta_step = 1 gives 69 beta grid values (apa_core.py:942 builds arange(beta_step, max_beta, beta_step) of any
+    length; ABI 3 refused more than 64): Phase B's generic path, 69-row alpha groups in the M-step tiles; whole fit vs
+    the oracle."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_chunk
+    kw = dict(n_max_apa=3, n_min_apa=1, beta_step=1)
+    chunk = synth_chunk(2, 300, k_cap=3, base_seed=909)
+    preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in chunk]
+    assert len(preps[0].betas) == 69
+    res = Engine(device=0).run(preps, rng_mode="per_utr", seed=21, re_run_mode=True)
+    for i, ((g, df), r) in enumerate(zip(chunk, res)):
+        np.random.seed(21 + i)
+        want, _m = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, re_run_mode=True, **kw)
+        para = to_parameters(r)
+        assert para.K == want.K and np.array_equal(para.alpha_arr, want.alpha_arr) and np.array_equal(para.beta_arr, want.beta_arr)
+        assert np.array_equal(para.label_arr, want.label_arr)
+        assert np.allclose(para.ws, want.ws, rtol=1e-8, atol=1e-12) and para.bic == pytest.approx(want.bic, rel=1e-9)
