@@ -911,6 +911,7 @@ __global__ __launch_bounds__(EM_THREADS) void k_em(
 
 #include "em_lockstep.inc"
 #include "mstep_ring.inc"
+#include "mstep_multi.inc"
 
 // ------------------------------------------------------------------------------------------
 // labels: get_label (apa_core.py:873-881), one workgroup per selected model
@@ -1014,7 +1015,7 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
-#define N_COUNTERS (4 + 5 * 64)   // rounds, slab elements (v1), z elements, unused, then five 64-way sharded counters (em_lockstep.inc)
+#define N_COUNTERS (4 + 5 * 64 + 16)   // (+16: ESTEP_STAMPS tools builds) rounds, slab elements (v1), z elements, unused, then five 64-way sharded counters (em_lockstep.inc)
 struct scape_hip_ctx {
     int device = 0;
     std::atomic<bool> busy{false};   // a handle serves one host thread at a time (scape_hip.h)
@@ -1217,6 +1218,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
     const bool job_split = (long long)n_active * tiles_max <= split_maxtiles;
     // M-step kernel: k3_mstep (LDS-DMA rings, mstep_ring.inc) unless SCAPE_HIP_MSTEP=v2 asks for the register-staged
     // k2_mstep (A/B runs; identical bits).  k3's DMA source offsets are 32-bit byte offsets from the start of the job vectors.
+    const bool debug_env = getenv("SCAPE_HIP_DEBUG") != nullptr;     // the tile / job histograms are k2 / k3 only
     const char *env_m = getenv("SCAPE_HIP_MSTEP");
     bool ring_mstep = !(env_m && strcmp(env_m, "v2") == 0);
     constexpr int pt_rows = MT_ROWS;
@@ -1238,6 +1240,11 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
         c->e_ujoff.ensure((c->n_utr + 1) * 8) || c->e_ujlist.ensure(nj * 4) || c->e_active.ensure((size_t)c->n_utr * 4))
         return 1;
     if (vtot * 8 >= ((size_t)1 << 31)) ring_mstep = false;
+    // k4_mstep (mstep_multi.inc): several tiles per workgroup, set-up and epilogue off the critical path - the kernel of
+    // wave-sized calls; calls with few live tiles keep k3_mstep with a tile's jobs cut into passes for several workgroups
+    const bool multi_mstep = ring_mstep && !job_split && !debug_env && pttot < ((size_t)1 << 31) && !(env_m && strcmp(env_m, "v3") == 0);
+    if (multi_mstep && M4_LDS_BYTES > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k4_mstep), hipFuncAttributeMaxDynamicSharedMemorySize, M4_LDS_BYTES));
     if (ring_mstep && M3_LDS_BYTES > 64 * 1024)   // per device; a few microseconds
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k3_mstep), hipFuncAttributeMaxDynamicSharedMemorySize, M3_LDS_BYTES));
     // The E-step gives XCD x the x-th eighth of its job list: with the jobs of UTR active[x], active[x + 8], ... there,
@@ -1382,7 +1389,14 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                    c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw,  \
                    S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, c->d_tile_nend.as<int32_t>(),                    \
                    c->d_counters.as<unsigned long long>(), jobs_per_pass, dbg
-                if (ring_mstep)
+                if (multi_mstep) {
+                    const int groups_max = (tiles_max + M4_TPW - 1) / M4_TPW;
+                    hipLaunchKernelGGL(k4_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * groups_max)), dim3(256), M4_LDS_BYTES, st,
+                                       c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, groups_max,
+                                       c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw,
+                                       S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, c->d_tile_nend.as<int32_t>(),
+                                       c->d_counters.as<unsigned long long>());
+                } else if (ring_mstep)
                     hipLaunchKernelGGL(k3_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max), psplit), dim3(256), M3_LDS_BYTES, st, MSTEP_ARGS);
                 else
                     hipLaunchKernelGGL(k2_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * tiles_max), psplit), dim3(256), 0, st, MSTEP_ARGS);
@@ -1852,6 +1866,15 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipStreamSynchronize(c->stream));
     if (finish_build(c)) return 1;        // a batch_build queued before this call: its flag is final now
     c->last_em_jobs = n_jobs;
+#ifdef ESTEP_STAMPS   // tools-only: where a k2_estep wavefront's lifetime goes (cycle sums over all job-rounds of the call)
+    {
+        const unsigned long long *st = hc + 4 + 5 * 64;
+        const double n = (double)st[7];
+        if (n > 0)
+            fprintf(stderr, "[estep stamps] job-rounds %.0f; mean cycles: set-up %.0f, bin loop %.0f, reductions+weights %.0f, suffix sums %.0f, tail %.0f (total %.0f)\n",
+                    n, st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, (st[0] + st[1] + st[2] + st[3] + st[4]) / n);
+    }
+#endif
     for (int i = 0; i < 3; ++i) c->h_counters[i] = hc[i];
     c->h_traffic[0] = c->h_traffic[1] = c->h_traffic[2] = 0;
     for (int i = 0; i < 64; ++i) {
