@@ -63,6 +63,7 @@ struct UtrDesc {
     int64_t log_off;    // first entry in the log-domain bin list
     int64_t tile_off;   // first entry of this UTR in the per-tile extent table (64-row tiles of M)
     int64_t mlog_off;   // first entry of this UTR in the compact table of log-domain values (phase_b_split.inc)
+    int32_t c_lo, c_hi; // uniform theta grid: the interior grid points [c_lo, c_hi] share one window table; c_lo > c_hi: none
     int32_t N, Np, T, n_log;
     double unif_ll, L, min_theta;
 };
@@ -1031,8 +1032,9 @@ struct scape_hip_ctx {
     std::vector<UtrDesc> h_desc;
     size_t at_total = 0, m_total = 0;
     DevBuf d_x, d_l, d_r, d_pa, d_cnt, d_theta, d_desc, d_loglist, d_AT, d_V, d_M, d_err, d_counters, d_tile_nend;
-    DevBuf d_tbi, d_tbpm, d_mlog;   // Phase B: window tables, compact log-domain values
-    size_t n_theta_total = 0, mlog_total = 0;
+    DevBuf d_tbi, d_tbG, d_tbpm, d_mlog, d_logbin;   // Phase B: window tables, compact log-domain values, log bin -> UTR
+    size_t n_theta_total = 0, mlog_total = 0, n_logbins = 0;
+    bool pb_slide = false;            // every UTR of the batch has a uniform theta grid with interior points: k_pb_logcol / k_pb_slide
     int tiles_max_all = 1;
     size_t tiles_total = 0;
     DevBuf j_utr, j_K, j_fixed, j_a, j_b, j_ws, j_karr, j_ao, j_bo, j_wso, j_bic, j_nlb, j_lb, j_sel, j_lbsel;
@@ -1489,7 +1491,7 @@ int scape_hip_device_name(scape_hip_ctx *c, char *buf, int buflen) {
 int scape_hip_batch_free(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
     CTX_ENTER(c);
-    DevBuf *all[] = {&c->d_tbi, &c->d_tbpm, &c->d_mlog, &c->d_tile_nend, &c->d_x, &c->d_l, &c->d_r, &c->d_pa, &c->d_cnt, &c->d_theta, &c->d_desc, &c->d_loglist,
+    DevBuf *all[] = {&c->d_tbi, &c->d_tbG, &c->d_tbpm, &c->d_mlog, &c->d_logbin, &c->d_tile_nend, &c->d_x, &c->d_l, &c->d_r, &c->d_pa, &c->d_cnt, &c->d_theta, &c->d_desc, &c->d_loglist,
                      &c->d_AT, &c->d_V, &c->d_M, &c->j_utr, &c->j_K, &c->j_fixed, &c->j_a, &c->j_b, &c->j_ws,
                      &c->j_karr, &c->j_ao, &c->j_bo, &c->j_wso, &c->j_bic, &c->j_nlb, &c->j_lb, &c->l_utr,
                      &c->l_K, &c->l_a, &c->l_b, &c->l_ws, &c->l_labels, &c->e_ia, &c->e_ib, &c->e_sia, &c->e_sib,
@@ -1669,6 +1671,8 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
     c->h_desc.assign(n_utr, UtrDesc());
     std::vector<int32_t> loglist;
     size_t at_total = 0, m_total = 0, tiles_total = 0, mlog_total = 0;
+    std::vector<int32_t> logbin_utr;
+    bool pb_slide = p->n_beta <= 16;
     int T_max = 0, Np_max = 0, W_max = 1, tiles_max_all = 1;
     for (int u = 0; u < n_utr; ++u) {
         UtrDesc &d = c->h_desc[u];
@@ -1696,6 +1700,20 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
         d.n_log = (int)(loglist.size() - (size_t)d.log_off);
         d.mlog_off = (int64_t)mlog_total;
         if (d.n_log > 0 && d.n_log <= PB_LOGCAP) mlog_total += (size_t)T * p->n_beta * d.n_log;
+        logbin_utr.insert(logbin_utr.end(), (size_t)d.n_log, (int32_t)u);
+        {   // uniform grid of integer values: theta_w - theta_i is exact and depends on w - i only
+            d.c_lo = 1;
+            d.c_hi = 0;
+            const double step0 = (T > 1) ? th[1] - th[0] : 0.0;
+            bool uni = step0 > 0.0;
+            for (int64_t i = 0; i < T && uni; ++i) uni = std::floor(th[i]) == th[i] && (i == 0 || th[i] - th[i - 1] == step0);
+            if (uni) {
+                const int rmax = (int)std::floor(3 * bmax / step0) + 1;     // reach of the widest window in grid points, + 1 to spare
+                d.c_lo = rmax + 1;
+                d.c_hi = (int)T - 2 - rmax;
+            }
+            if (d.c_lo > d.c_hi) pb_slide = false;
+        }
         d.unif_ll = unif_ll[u];
         d.L = utr_L[u];
         d.min_theta = min_theta[u];
@@ -1717,6 +1735,8 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
     c->tiles_max_all = tiles_max_all;
     c->n_theta_total = (size_t)nt;
     c->mlog_total = mlog_total;
+    c->n_logbins = logbin_utr.size();
+    c->pb_slide = pb_slide && W_max <= 4 * PB_STEPS && T_max <= 4096;
     const bool trace_load = getenv("SCAPE_HIP_DEBUG") != nullptr;
     const auto t_alloc0 = std::chrono::steady_clock::now();
     if (c->d_x.ensure(nb * 8) || c->d_l.ensure(nb * 8) || c->d_r.ensure(nb * 8) || c->d_pa.ensure(nb * 8) ||
@@ -1726,8 +1746,11 @@ int scape_hip_batch_load(scape_hip_ctx *c, const scape_hip_params *p, int32_t n_
         return 1;
     if (p->n_beta <= 16) {   // the three-kernel Phase B (phase_b_split.inc)
         const size_t WP = (size_t)(((W_max + 3) & ~3) + 1);
-        if (c->d_tbi.ensure((size_t)nt * 40 * 4) || c->d_tbpm.ensure((size_t)nt * 16 * WP * 8) || c->d_mlog.ensure(mlog_total * 8))
+        if (c->d_tbi.ensure((size_t)nt * 40 * 4) || c->d_tbG.ensure((size_t)nt * 16 * 8) || c->d_tbpm.ensure((size_t)nt * 16 * WP * 8) ||
+            c->d_mlog.ensure(mlog_total * 8) || c->d_logbin.ensure(logbin_utr.size() * 4))
             return 1;
+        if (!logbin_utr.empty())
+            HIPCHK(hipMemcpyAsync(c->d_logbin.p, logbin_utr.data(), logbin_utr.size() * 4, hipMemcpyHostToDevice, c->stream));
     }
     const auto t_up0 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(c->d_x.p, x, nb * 8, hipMemcpyHostToDevice, c->stream));
@@ -1775,11 +1798,13 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
     if (ev_end(c, 0)) return 1;
     if (ev_begin(c, 1)) return 1;
     HIPCHK(hipMemsetAsync(c->d_tile_nend.p, 0, c->tiles_total * 4, c->stream));   // Phase B raises the extents by atomicMax
-    // (measured, round 3: tables + log-domain bins 10.2 ms - the log path's gather of A[w][n] at a row pitch of 8.5 KB keeps
-    // the texture addresser busy - and the matrix path 10.9 ms, against 15.0 ms for k_phase_b: opt-in until the matrix
-    // path reads its V rows from LDS)
-    if (c->prm.B <= 16 && getenv("SCAPE_HIP_PHASE_B_SPLIT")) {
-        // tables -> log-domain bins -> matrix path with whole-line stores (phase_b_split.inc)
+    // SCAPE_HIP_PHASE_B = v2: k_phase_b (one kernel); split: tables + log bins, then the matrix path per alpha (measured,
+    // round 3: 10.2 + 10.9 ms against 15.0 for k_phase_b - the log path's gather of A[w][n] at a row pitch of 8.5 KB keeps
+    // the texture addresser busy); default where every theta grid is uniform: tables, log-bin columns, sliding windows
+    const char *pbm = getenv("SCAPE_HIP_PHASE_B");
+    const bool pb_v2 = pbm && strcmp(pbm, "v2") == 0, pb_split = pbm && strcmp(pbm, "split") == 0;
+    if (c->prm.B <= 16 && !pb_v2 && (pb_split || c->pb_slide)) {
+        const bool slide = c->pb_slide && !pb_split;
         if (c->d_err.ensure(sizeof(int))) return 1;
         HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
         const int Wmax = c->W_max, WP = ((Wmax + 3) & ~3) + 1, B = c->prm.B;
@@ -1787,14 +1812,31 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
         const size_t lds_l = ((size_t)16 * WP + 16 * PB_LOGCAP) * sizeof(double) + PB_LOGCAP * sizeof(int);
         if (lds_t > 60 * 1024 || lds_l > 60 * 1024) return fail("Phase B: window table does not fit LDS (n_beta x window too large)");
         hipLaunchKernelGGL(k_pb_tables<16>, dim3((unsigned)c->T_max, (unsigned)c->n_utr), dim3(PB_TAB_THREADS), lds_t, c->stream,
-                           c->d_desc.as<UtrDesc>(), c->prm, c->d_theta.as<double>(), Wmax, WP, c->d_tbi.as<int32_t>(),
-                           c->d_tbpm.as<double>(), c->d_err.as<int>(), c->T_max, c->d_loglist.as<int32_t>(), c->d_AT.as<double>(),
+                           c->d_desc.as<UtrDesc>(), c->prm, c->d_theta.as<double>(), Wmax, WP, c->d_tbi.as<int32_t>(), c->d_tbG.as<double>(),
+                           c->d_tbpm.as<double>(), c->d_err.as<int>(), c->T_max, slide ? nullptr : c->d_loglist.as<int32_t>(), c->d_AT.as<double>(),
                            c->d_M.as<double>(), c->d_mlog.as<double>(), c->d_tile_nend.as<int32_t>());
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_phase_b_lin, dim3((unsigned)(((c->n_utr + 7) / 8) * 8 * c->T_max)), dim3(256), lds_l, c->stream,
-                           c->d_desc.as<UtrDesc>(), c->prm, c->d_r.as<double>(), c->d_pa.as<double>(), c->d_loglist.as<int32_t>(),
-                           c->d_V.as<double>(), c->d_M.as<double>(), c->d_mlog.as<double>(), WP, c->d_tbi.as<int32_t>(),
-                           c->d_tbpm.as<double>(), c->n_utr, c->T_max, c->d_tile_nend.as<int32_t>());
+        if (slide) {
+            if (c->n_logbins) {
+                const size_t lds_c = ((size_t)((c->T_max + 1) & ~1) + (size_t)B * Wmax) * sizeof(double) + 16 * sizeof(int);
+                hipLaunchKernelGGL(k_pb_logcol, dim3((unsigned)c->n_logbins), dim3(256), lds_c, c->stream, c->d_desc.as<UtrDesc>(), c->prm,
+                                   c->d_theta.as<double>(), c->d_loglist.as<int32_t>(), c->d_logbin.as<int32_t>(), c->d_AT.as<double>(),
+                                   c->d_tbi.as<int32_t>(), c->d_tbG.as<double>(), c->d_M.as<double>(), c->d_mlog.as<double>(),
+                                   c->d_tile_nend.as<int32_t>(), Wmax);
+                HIPCHK(hipGetLastError());
+            }
+            const int blocks_max = (c->Np_max + 63) / 64;
+            const size_t lds_s = ((size_t)16 * WP + 4 * PB_RING * 16) * sizeof(double);
+            hipLaunchKernelGGL(k_pb_slide, dim3((unsigned)(((c->n_utr + 7) / 8) * 8 * blocks_max)), dim3(256), lds_s, c->stream,
+                               c->d_desc.as<UtrDesc>(), c->prm, c->d_r.as<double>(), c->d_pa.as<double>(), c->d_loglist.as<int32_t>(),
+                               c->d_V.as<double>(), c->d_M.as<double>(), c->d_mlog.as<double>(), WP, c->d_tbi.as<int32_t>(),
+                               c->d_tbpm.as<double>(), c->n_utr, blocks_max, c->d_tile_nend.as<int32_t>());
+        } else {
+            hipLaunchKernelGGL(k_phase_b_lin, dim3((unsigned)(((c->n_utr + 7) / 8) * 8 * c->T_max)), dim3(256), lds_l, c->stream,
+                               c->d_desc.as<UtrDesc>(), c->prm, c->d_r.as<double>(), c->d_pa.as<double>(), c->d_loglist.as<int32_t>(),
+                               c->d_V.as<double>(), c->d_M.as<double>(), c->d_mlog.as<double>(), WP, c->d_tbi.as<int32_t>(),
+                               c->d_tbpm.as<double>(), c->n_utr, c->T_max, c->d_tile_nend.as<int32_t>());
+        }
         HIPCHK(hipGetLastError());
     } else if (launch_phase_b(c, c->prm, c->n_utr, c->T_max, c->W_max, c->d_desc.as<UtrDesc>(), c->d_r.as<double>(),
                        c->d_pa.as<double>(), c->d_theta.as<double>(), c->d_loglist.as<int32_t>(),
