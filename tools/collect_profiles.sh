@@ -7,11 +7,11 @@ ROOT=$(pwd)   # summaries are also written under gpurun_out/<tag>/ (gpurun merge
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --e2e-utrs 0"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --e2e-utrs 0 --no-other-configs"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats_bench.json" 2> "$OUT/stats.err" )
 python3 tools/rocprof_summary.py stats "$OUT/stats" "profiles/${TAG}_kernel_stats.csv" "python3 bench.py $ARGS"
 cp "$OUT/stats_bench.json" "profiles/${TAG}_bench_under_rocprof.json"
-ARGS1="--steps 1 --warmup 0 --no-cpu-baseline --e2e-utrs 0"
+ARGS1="--steps 1 --warmup 0 --no-cpu-baseline --e2e-utrs 0 --no-other-configs"
 for C in "$@"; do
   N=$(echo "$C" | tr ' ,' '__')
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" $ARGS1 > "$OUT/pmc_$N.json" 2> "$OUT/pmc_$N.err" )
