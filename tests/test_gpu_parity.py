@@ -1019,3 +1019,91 @@ def test_beta_step_one_vs_oracle(oracle):
         assert para.K == want.K and np.array_equal(para.alpha_arr, want.alpha_arr) and np.array_equal(para.beta_arr, want.beta_arr)
         assert np.array_equal(para.label_arr, want.label_arr)
         assert np.allclose(para.ws, want.ws, rtol=1e-8, atol=1e-12) and para.bic == pytest.approx(want.bic, rel=1e-9)
+
+
+def test_phase_b_variants_give_identical_tensors(hip_ctx, monkeypatch):
+    """Phase B has three forms: k_phase_b (one kernel: the operator seam, non-uniform theta grids, > 16 beta values),
+    tables + per-alpha matrix path (SCAPE_HIP_PHASE_B=split) and - the default on uniform grids - tables + log-bin
+    columns + per-wavefront sliding windows.  They restate the same sums in the same order: the tensors must be equal
+    bit for bit, and so must an EM call on them (which also reads the tile extents each variant raises) - on UTRs with
+    few / many (> PB_LOGCAP = 64, written straight into the tensor) / only log-domain bins, r-known reads, one bin, a
+    9 kb UTR."""
+    from scape_amd.engine import HipBatch, _Job
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    rng = np.random.default_rng(17)
+
+    def mk(x, l, r=None, pa=None):
+        n = len(x)
+        return pd.DataFrame({"x": np.asarray(x, dtype=np.int64), "l": np.asarray(l, dtype=np.int64),
+                             "r": np.full(n, np.nan) if r is None else r, "pa": np.full(n, np.nan) if pa is None else pa,
+                             "cb_id": np.arange(n), "read_id": np.arange(n)})
+    dfs = [synth_utr(i, 700, k_cap=4, base_seed=515, pa_rate=rate, r_rate=rr)[1]
+           for i, (rate, rr) in enumerate([(0.015, 0.0), (0.0, 0.0), (0.4, 0.0), (0.02, 0.1), (0.015, 0.0)])]
+    dfs += [mk(rng.integers(300, 600, 150), rng.integers(31, 133, 150), pa=rng.integers(700, 760, 150).astype(float)),
+            mk([400] * 120, [98] * 120), mk(rng.integers(0, 9000, 400), rng.integers(31, 133, 400))]
+    preps = [prepare_utr(df, gene_info_str=f"syn:PB{i}:1:1-9999:+", n_max_apa=3) for i, df in enumerate(dfs)]
+    n_log = [int((~np.isnan(q.pa) | ~np.isnan(q.r)).sum()) for q in preps]
+    assert min(n_log) == 0 and max(n_log) > 64 and any(0 < v <= 64 for v in n_log), n_log
+    jobs = []
+    for u, q in enumerate(preps):
+        for K in (1, 2, 3):
+            a = np.sort(rng.choice(q.T, K, replace=False)).astype(np.int32)
+            w = rng.dirichlet(np.ones(K + 1))
+            ka = (np.arange(50) % K).astype(np.int8)
+            jobs.append(_Job(u, K, False, a, rng.integers(0, len(q.betas), K).astype(np.int32), w, ka))
+    out = {}
+    for mode in ("v2", "split", None):
+        if mode is None:
+            monkeypatch.delenv("SCAPE_HIP_PHASE_B", raising=False)
+        else:
+            monkeypatch.setenv("SCAPE_HIP_PHASE_B", mode)
+        batch = HipBatch(hip_ctx, preps)
+        batch.build()
+        tensors = [batch.fetch_tensor(u) for u in range(len(preps))]
+        fits = batch.em(jobs)
+        out[mode] = (tensors, [(f.K, f.a_idx.tobytes(), f.b_idx.tobytes(), f.ws.tobytes(), f.bic, f.lb.tobytes()) for f in fits])
+        batch.free()
+    for mode in ("split", None):
+        for u, (a, b) in enumerate(zip(out["v2"][0], out[mode][0])):
+            assert np.array_equal(a, b), (mode, u, int((a != b).sum()))
+        assert out["v2"][1] == out[mode][1], mode
+
+
+def test_mstep_kernels_give_identical_bits(hip_ctx, monkeypatch):
+    """The M-step has three kernels - k2_mstep (register-staged, SCAPE_HIP_MSTEP=v2), k3_mstep (LDS-DMA rings, one tile
+    per workgroup, v3) and k4_mstep (two tiles per workgroup, job slots ranked by support; the default of wave-sized
+    calls).  Every score is the same chain of MFMAs in all of them: the same jobs must come back bit for bit - K = 1..10
+    (one to four column groups per tile, tiles with more than 64 jobs: passes) on UTRs of different sizes."""
+    from scape_amd.engine import Engine, HipBatch
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    monkeypatch.setenv("SCAPE_HIP_SPLIT_MAXTILES", "0")        # never cut a tile's jobs into passes for several workgroups
+    monkeypatch.setenv("SCAPE_HIP_WIDE_MAXJOBS", "0")
+    kw = dict(n_max_apa=10, n_min_apa=1)
+    preps = [prepare_utr(df, gene_info_str=g, **kw)
+             for g, df, _ in (synth_utr(i, reads, k_cap=5, base_seed=6100) for i, reads in enumerate((1500, 400, 2500, 900, 1200, 700, 1800, 300, 1000)))]
+    eng = Engine(device=0)
+    plan = eng.plan(preps, [(6100 + i) % 2 ** 32 for i in range(len(preps))])
+    pj = plan["main"]
+    # more than 64 jobs on the tiles of UTR 0: its sweep three times over in one call
+    from scape_amd.engine import concat_packed, PackedJobs
+    lo, hi = int(plan["spans"][0]), int(plan["spans"][1])
+    first = PackedJobs(pj.ju[lo:hi], pj.jk[lo:hi], pj.jf[lo:hi], pj.a[lo:hi], pj.b[lo:hi], pj.w[lo:hi], pj.ka[lo:hi])
+    big = concat_packed([pj, first, first])
+    batch = HipBatch(hip_ctx, preps)
+    batch.build()
+    got = {}
+    for mode in ("v2", "v3", None):
+        if mode is None:
+            monkeypatch.delenv("SCAPE_HIP_MSTEP", raising=False)
+        else:
+            monkeypatch.setenv("SCAPE_HIP_MSTEP", mode)
+        got[mode] = [np.array(x).copy() for x in batch.em_packed(big)]
+    batch.free()
+    for mode in ("v3", None):
+        for x, y in zip(got["v2"], got[mode]):
+            assert np.array_equal(x, y), mode
+    n = len(pj)
+    for x in got[None]:                                     # the repeated jobs came back like their originals
+        assert np.array_equal(x[n:n + (hi - lo)], x[lo:hi]) and np.array_equal(x[n + (hi - lo):], x[lo:hi])
