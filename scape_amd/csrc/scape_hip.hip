@@ -1018,7 +1018,7 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
-#define N_COUNTERS (4 + 5 * 64 + 16)   // (+16: ESTEP_STAMPS tools builds) rounds, slab elements (v1), z elements, unused, then five 64-way sharded counters (em_lockstep.inc)
+#define N_COUNTERS (4 + 5 * 64 + 16 + 48)   // (+16: ESTEP_STAMPS, +48: M4_STAMPS tools builds) rounds, slab elements (v1), z elements, unused, then five 64-way sharded counters (em_lockstep.inc)
 struct scape_hip_ctx {
     int device = 0;
     std::atomic<bool> busy{false};   // a handle serves one host thread at a time (scape_hip.h)
@@ -1942,6 +1942,19 @@ int scape_hip_batch_em(scape_hip_ctx *c, int32_t n_jobs, int32_t kmax, const int
     HIPCHK(hipStreamSynchronize(c->stream));
     if (finish_build(c)) return 1;        // a batch_build queued before this call: its flag is final now
     c->last_em_jobs = n_jobs;
+#ifdef M4_STAMPS   // tools-only: k4_mstep's half-chunk iterations by running column groups and wavefront role (whole call)
+    {
+        const unsigned long long *st = hc + 4 + 5 * 64 + 16;
+        for (int ga = 0; ga < 4; ++ga)
+            for (int role = 0; role < 2; ++role) {
+                const double n = (double)st[32 + ga * 2 + role];
+                const unsigned long long *v = st + 4 * (ga * 2 + role);
+                if (n > 0)
+                    fprintf(stderr, "[mstep stamps] %d running groups, %s wavefronts: %.3g iterations; mean cycles: dma wait %.0f, barrier %.0f, issue %.0f, reads+mfma %.0f (total %.0f)\n",
+                            ga + 1, role ? "vector" : "tile", n, v[0] / n, v[1] / n, v[2] / n, v[3] / n, (v[0] + v[1] + v[2] + v[3]) / n);
+            }
+    }
+#endif
 #ifdef ESTEP_STAMPS   // tools-only: where a k2_estep wavefront's lifetime goes (cycle sums over all job-rounds of the call)
     {
         const unsigned long long *st = hc + 4 + 5 * 64;
