@@ -1397,7 +1397,7 @@ static int em_lockstep(scape_hip_ctx *c, int n_jobs, int kmax, const int32_t *jo
                    c->d_counters.as<unsigned long long>(), jobs_per_pass, dbg
                 if (multi_mstep) {
                     const int groups_max = (tiles_max + M4_TPW - 1) / M4_TPW;
-                    hipLaunchKernelGGL(k4_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * groups_max)), dim3(256), M4_LDS_BYTES, st,
+                    hipLaunchKernelGGL(k4_mstep, dim3((unsigned)(((nu + 7) / 8) * 8 * groups_max)), dim3(64 * M4_NW), M4_LDS_BYTES, st,
                                        c->d_desc.as<UtrDesc>(), c->prm, c->d_M.as<double>(), c->e_active.as<int32_t>() + g_a0[g], nu, groups_max,
                                        c->e_ujoff.as<int64_t>(), c->e_ujlist.as<int32_t>(), S.V, S.Vsuf, S.voff, S.rd_m, S.rd_lo, S.rd_hi, S.rd_lw,
                                        S.rd_sv, S.rd_n0, S.rd_n1, S.ptoff, S.pt_score, S.pt_row, c->d_tile_nend.as<int32_t>(),
