@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libscape_hip.so lacks {name}"
     assert declared == set(_lib.SIGNATURES), "ctypes table and header disagree"
-    assert lib.scape_hip_abi_version() == 3
+    assert lib.scape_hip_abi_version() == 4
 
 
 def test_host_library_exports_every_declared_symbol():
