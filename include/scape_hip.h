@@ -104,6 +104,10 @@ int scape_hip_batch_bytes(scape_hip_ctx *ctx, int64_t *bytes_batch, int64_t *byt
    not awaited: the next call on the context runs behind them, and a device-side consistency failure of the build is
    reported by that call (batch_em / batch_labels / batch_fetch_*). */
 int scape_hip_batch_build(scape_hip_ctx *ctx);
+/* which form of Phase B the last batch_build queued (diagnostics / tests; the results do not depend on it):
+   0 = one kernel (the form of get_loglik_marginal_tensor; non-uniform theta grids, > 16 beta values),
+   1 = window tables + per-alpha matrix path, 2 = window tables + log-bin columns + sliding windows (uniform theta grids) */
+int scape_hip_batch_phase_b_form(scape_hip_ctx *ctx, int32_t *form);
 /*
  * n_jobs em_algo calls (apa_core.py:714-779).  Job j works on UTR job_utr[j] with job_K[j]
  * components from the init (alpha_idx, beta_idx = indices into that UTR's all_theta / betas,

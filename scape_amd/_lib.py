@@ -49,6 +49,7 @@ SIGNATURES = {
     "scape_hip_batch_load": (c_i, [P_void, ctypes.POINTER(Params), c_i32, P_i64, P_d, P_d, P_d, P_d, P_d,
                                    P_i64, P_d, P_d, P_d, P_d]),
     "scape_hip_batch_bytes": (c_i, [P_void, P_i64, P_i64, P_i64]),
+    "scape_hip_batch_phase_b_form": (c_i, [P_void, P_i32]),
     "scape_hip_batch_build": (c_i, [P_void]),
     "scape_hip_batch_em": (c_i, [P_void, c_i32, c_i32, P_i32, P_i32, P_i32, P_i32, P_i32, P_d, P_i8,
                                  P_i32, P_i32, P_d, P_d, P_i32, P_d]),

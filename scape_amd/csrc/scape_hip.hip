@@ -1034,6 +1034,7 @@ struct scape_hip_ctx {
     DevBuf d_x, d_l, d_r, d_pa, d_cnt, d_theta, d_desc, d_loglist, d_AT, d_V, d_M, d_err, d_counters, d_tile_nend;
     DevBuf d_tbi, d_tbG, d_tbpm, d_mlog, d_logbin;   // Phase B: window tables, compact log-domain values, log bin -> UTR
     size_t n_theta_total = 0, mlog_total = 0, n_logbins = 0;
+    int pb_form = 0;                  // Phase B form of the last batch_build (scape_hip_batch_phase_b_form)
     bool pb_slide = false;            // every UTR of the batch has a uniform theta grid with interior points: k_pb_logcol / k_pb_slide
     int tiles_max_all = 1;
     size_t tiles_total = 0;
@@ -1784,6 +1785,12 @@ int scape_hip_batch_bytes(scape_hip_ctx *c, int64_t *bytes_batch, int64_t *bytes
     return 0;
 }
 
+int scape_hip_batch_phase_b_form(scape_hip_ctx *c, int32_t *form) {
+    if (!c || !form) return fail("ctx / form is NULL");
+    *form = c->pb_form;
+    return 0;
+}
+
 int scape_hip_batch_build(scape_hip_ctx *c) {
     if (!c) return fail("ctx is NULL");
     if (!c->loaded) return fail("no batch loaded");
@@ -1805,6 +1812,7 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
     const bool pb_v2 = pbm && strcmp(pbm, "v2") == 0, pb_split = pbm && strcmp(pbm, "split") == 0;
     if (c->prm.B <= 16 && !pb_v2 && (pb_split || c->pb_slide)) {
         const bool slide = c->pb_slide && !pb_split;
+        c->pb_form = slide ? 2 : 1;
         if (c->d_err.ensure(sizeof(int))) return 1;
         HIPCHK(hipMemsetAsync(c->d_err.p, 0, sizeof(int), c->stream));
         const int Wmax = c->W_max, WP = ((Wmax + 3) & ~3) + 1, B = c->prm.B;
@@ -1838,7 +1846,7 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
                                c->d_tbpm.as<double>(), c->n_utr, c->T_max, c->d_tile_nend.as<int32_t>());
         }
         HIPCHK(hipGetLastError());
-    } else if (launch_phase_b(c, c->prm, c->n_utr, c->T_max, c->W_max, c->d_desc.as<UtrDesc>(), c->d_r.as<double>(),
+    } else if ((c->pb_form = 0), launch_phase_b(c, c->prm, c->n_utr, c->T_max, c->W_max, c->d_desc.as<UtrDesc>(), c->d_r.as<double>(),
                        c->d_pa.as<double>(), c->d_theta.as<double>(), c->d_loglist.as<int32_t>(),
                        c->d_AT.as<double>(), c->d_V.as<double>(), c->d_M.as<double>(), 0, c->d_tile_nend.as<int32_t>()))
         return 1;

@@ -145,6 +145,12 @@ class HipBatch:
     def build(self):
         check(self.lib.scape_hip_batch_build(self.ctx.h), "batch_build")
 
+    def phase_b_form(self):
+        """Which Phase B form the last build() queued (0 one kernel, 1 tables + per-alpha, 2 sliding windows)."""
+        form = ctypes.c_int32(-1)
+        check(self.lib.scape_hip_batch_phase_b_form(self.ctx.h, ctypes.byref(form)), "batch_phase_b_form")
+        return int(form.value)
+
     def em_packed(self, pj, reuse_buffers=False, want_lb=True):
         """Run em_algo for packed job tables; returns (alpha_idx, beta_idx, ws, bic, n_lb, lb) arrays.
         reuse_buffers: hand out the same host arrays on every call of this shape (the caller must be

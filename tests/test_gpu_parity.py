@@ -1045,6 +1045,15 @@ def test_phase_b_variants_give_identical_tensors(hip_ctx, monkeypatch):
     preps = [prepare_utr(df, gene_info_str=f"syn:PB{i}:1:1-9999:+", n_max_apa=3) for i, df in enumerate(dfs)]
     n_log = [int((~np.isnan(q.pa) | ~np.isnan(q.r)).sum()) for q in preps]
     assert min(n_log) == 0 and max(n_log) > 64 and any(0 < v <= 64 for v in n_log), n_log
+    _phase_b_variants_check(hip_ctx, monkeypatch, preps, rng)
+    # other uniform grids: the interior block of four, the 11- and 12-step forms, windows much narrower than the ring
+    for kw in ({"theta_step": 15}, {"theta_step": 6, "max_beta": 45}, {"theta_step": 8, "max_beta": 65}, {"theta_step": 21, "max_beta": 80, "beta_step": 10}):
+        preps = [prepare_utr(df, gene_info_str=f"syn:PB{i}:1:1-9999:+", n_max_apa=3, **kw) for i, df in enumerate(dfs[:4] + dfs[-1:])]
+        _phase_b_variants_check(hip_ctx, monkeypatch, preps, rng)
+
+
+def _phase_b_variants_check(hip_ctx, monkeypatch, preps, rng):
+    from scape_amd.engine import HipBatch, _Job
     jobs = []
     for u, q in enumerate(preps):
         for K in (1, 2, 3):
@@ -1060,6 +1069,7 @@ def test_phase_b_variants_give_identical_tensors(hip_ctx, monkeypatch):
             monkeypatch.setenv("SCAPE_HIP_PHASE_B", mode)
         batch = HipBatch(hip_ctx, preps)
         batch.build()
+        assert batch.phase_b_form() == {"v2": 0, "split": 1, None: 2}[mode]
         tensors = [batch.fetch_tensor(u) for u in range(len(preps))]
         fits = batch.em(jobs)
         out[mode] = (tensors, [(f.K, f.a_idx.tobytes(), f.b_idx.tobytes(), f.ws.tobytes(), f.bic, f.lb.tobytes()) for f in fits])
