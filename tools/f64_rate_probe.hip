@@ -1,0 +1,81 @@
+// f64_rate_probe.hip - what the f64 pipes of a gfx950 SIMD deliver (tools only, not part of the product):
+//   v_mfma_f64_16x16x4_f64 in one dependent chain / in four independent chains, v_fma_f64 in eight independent chains,
+//   and both kinds side by side from different wavefronts of a SIMD (do they overlap?).
+//   hipcc --offload-arch=gfx950 -O3 -o build/f64_rate_probe tools/f64_rate_probe.hip && build/f64_rate_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// MODE 0: one MFMA chain; 1: four MFMA chains; 2: eight FMA chains; 3: blocks of 8 wavefronts - 0-3 MFMA (4 chains), 4-7 FMA
+// (wavefronts w and w + 4 of a workgroup share a SIMD)
+template <int MODE>
+__global__ __launch_bounds__(512) void k_rate(double *out, int iters, double x, double y) {
+    const int wave = threadIdx.x >> 6;
+    const bool do_mfma = MODE <= 1 || (MODE == 3 && wave < 4);
+    double res = 0.0;
+    if (do_mfma) {
+        v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        for (int i = 0; i < iters; ++i) {
+            if (MODE == 0) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+            } else {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+            }
+        }
+        res = a0[0] + a1[1] + a2[2] + a3[3];
+    } else {
+        double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) c[q] = __builtin_fma(x, y, c[q]);      // 32 v_fma_f64 per iteration
+        for (int q = 0; q < 8; ++q) res += c[q];
+    }
+    if (res == 1234.5) out[blockIdx.x] = res;
+}
+
+template <int MODE>
+static void run(const char *name, int waves_per_simd, double *out) {
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a));
+    CHK(hipEventCreate(&b));
+    const int iters = 20000, threads = MODE == 3 ? 512 : 256;
+    const int blocks = 256 * waves_per_simd / (threads / 256);    // 4 wavefronts per 256 threads = one per SIMD of a CU
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_rate<MODE>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0000001, 0.9999999);
+        CHK(hipEventRecord(b));
+        CHK(hipEventSynchronize(b));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best;
+    }
+    const double waves = (double)blocks * (threads / 64), simds = 1024.0;
+    // per SIMD: instructions issued by its wavefronts
+    const double mfma_w = (MODE <= 1 ? waves : (MODE == 3 ? waves / 2 : 0)), fma_w = (MODE == 2 ? waves : (MODE == 3 ? waves / 2 : 0));
+    const double n_mfma = mfma_w * iters * 4 / simds, n_fma = fma_w * iters * 32 / simds;
+    printf("%-58s %d wave(s)/SIMD  %.3f ms", name, waves_per_simd, best);
+    if (n_mfma > 0) printf("  %.1f ns per MFMA per SIMD (%.1f TFLOP/s)", best * 1e6 / n_mfma, mfma_w * iters * 4 * 2048.0 / best / 1e9);
+    if (n_fma > 0) printf("  %.2f ns per FMA per SIMD (%.1f TFLOP/s)", best * 1e6 / n_fma, fma_w * iters * 32 * 128.0 / best / 1e9);
+    printf("\n");
+}
+
+int main() {
+    double *out;
+    CHK(hipMalloc(&out, 1 << 20));
+    for (int w : {1, 2, 4}) run<0>("MFMA f64 16x16x4, one dependent chain", w, out);
+    for (int w : {1, 2, 4}) run<1>("MFMA f64 16x16x4, four independent chains", w, out);
+    for (int w : {1, 2, 4}) run<2>("v_fma_f64, eight independent chains", w, out);
+    for (int w : {2, 4}) run<3>("MFMA wavefronts beside v_fma_f64 wavefronts on the same SIMDs", w, out);
+    return 0;
+}
