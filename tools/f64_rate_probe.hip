@@ -8,15 +8,34 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// MODE 4: as 1, but every MFMA of the loop body reads A / B register pairs of its own (16 of each), as a kernel whose operands come fresh from LDS
 // MODE 0: one MFMA chain; 1: four MFMA chains; 2: eight FMA chains; 3: blocks of 8 wavefronts - 0-3 MFMA (4 chains), 4-7 FMA
 // (wavefronts w and w + 4 of a workgroup share a SIMD)
 template <int MODE>
 __global__ __launch_bounds__(512) void k_rate(double *out, int iters, double x, double y) {
     const int wave = threadIdx.x >> 6;
-    const bool do_mfma = MODE <= 1 || (MODE == 3 && wave < 4);
+    const bool do_mfma = MODE <= 1 || MODE == 4 || (MODE == 3 && wave < 4);
     double res = 0.0;
     if (do_mfma) {
         v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        if (MODE == 4) {
+            double xa[16], yb[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                xa[q] = x + 1e-9 * (q + threadIdx.x);
+                yb[q] = y - 1e-9 * (q + threadIdx.x);
+                asm volatile("" : "+v"(xa[q]), "+v"(yb[q]));
+            }
+            for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+                for (int q = 0; q < 16; q += 4) {
+                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q], yb[q], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q + 1], yb[q + 1], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q + 2], yb[q + 2], a2, 0, 0, 0);
+                    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q + 3], yb[q + 3], a3, 0, 0, 0);
+                }
+            }
+        } else
         for (int i = 0; i < iters; ++i) {
             if (MODE == 0) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
@@ -62,7 +81,7 @@ static void run(const char *name, int waves_per_simd, double *out) {
     }
     const double waves = (double)blocks * (threads / 64), simds = 1024.0;
     // per SIMD: instructions issued by its wavefronts
-    const double mfma_w = (MODE <= 1 ? waves : (MODE == 3 ? waves / 2 : 0)), fma_w = (MODE == 2 ? waves : (MODE == 3 ? waves / 2 : 0));
+    const double mfma_w = (MODE <= 1 || MODE == 4 ? waves : (MODE == 3 ? waves / 2 : 0)), fma_w = (MODE == 2 ? waves : (MODE == 3 ? waves / 2 : 0));
     const double n_mfma = mfma_w * iters * 4 / simds, n_fma = fma_w * iters * 32 / simds;
     printf("%-58s %d wave(s)/SIMD  %.3f ms", name, waves_per_simd, best);
     if (n_mfma > 0) printf("  %.1f ns per MFMA per SIMD (%.1f TFLOP/s)", best * 1e6 / n_mfma, mfma_w * iters * 4 * 2048.0 / best / 1e9);
@@ -75,6 +94,7 @@ int main() {
     CHK(hipMalloc(&out, 1 << 20));
     for (int w : {1, 2, 4}) run<0>("MFMA f64 16x16x4, one dependent chain", w, out);
     for (int w : {1, 2, 4}) run<1>("MFMA f64 16x16x4, four independent chains", w, out);
+    for (int w : {1, 2, 4}) run<4>("MFMA f64 16x16x4, four chains, 16 A / B register pairs", w, out);
     for (int w : {1, 2, 4}) run<2>("v_fma_f64, eight independent chains", w, out);
     for (int w : {2, 4}) run<3>("MFMA wavefronts beside v_fma_f64 wavefronts on the same SIMDs", w, out);
     return 0;
