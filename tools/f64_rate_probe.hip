@@ -89,6 +89,69 @@ static void run(const char *name, int waves_per_simd, double *out) {
     printf("\n");
 }
 
+
+// one VALU instruction in eight independent chains (32 per iteration), 4 wavefronts per SIMD
+#define OPK(NAME, ASM)                                                                                     \
+__global__ __launch_bounds__(256) void NAME(double *out, int iters, double x, double y) {                  \
+    double c[8];                                                                                           \
+    for (int q = 0; q < 8; ++q) c[q] = x + q * 1e-3 + threadIdx.x * 1e-6;                                  \
+    int e = (int)(threadIdx.x & 3);                                                                        \
+    for (int i = 0; i < iters; ++i)                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile(ASM : "+v"(c[q]) : "v"(y), "v"(e)); \
+    double res = 0;                                                                                        \
+    for (int q = 0; q < 8; ++q) res += c[q];                                                               \
+    if (res == 1234.5) out[blockIdx.x] = res;                                                              \
+}
+OPK(k_add, "v_add_f64 %0, %0, %1")
+OPK(k_mul, "v_mul_f64 %0, %0, %1")
+OPK(k_max, "v_max_f64 %0, %0, %1")
+OPK(k_ldexp, "v_ldexp_f64 %0, %0, %2")
+OPK(k_rndne, "v_rndne_f64 %0, %0")
+OPK(k_rcp, "v_rcp_f64 %0, %0")
+OPK(k_frexp, "v_frexp_mant_f64 %0, %0")
+OPK(k_mov64, "v_mov_b64 %0, %1")
+#define OPK32(NAME, ASM)                                                                                   \
+__global__ __launch_bounds__(256) void NAME(double *out, int iters, double x, double y) {                  \
+    int c[8];                                                                                              \
+    for (int q = 0; q < 8; ++q) c[q] = (int)threadIdx.x + q;                                               \
+    int e = (int)(threadIdx.x & 3);                                                                        \
+    for (int i = 0; i < iters; ++i)                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                      \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) asm volatile(ASM : "+v"(c[q]) : "v"(e));         \
+    int res = 0;                                                                                           \
+    for (int q = 0; q < 8; ++q) res += c[q];                                                               \
+    if (res == 12345) out[blockIdx.x] = res;                                                               \
+}
+OPK32(k_cnd, "v_cndmask_b32 %0, %0, %1, vcc")
+OPK32(k_add32, "v_add_u32 %0, %0, %1")
+OPK32(k_cnd64, "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+OPK32(k_cmpcnd, "v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc")
+OPK32(k_cmpcnd64, "v_cmp_gt_u32 s[10:11], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+OPK32(k_cmp32, "v_cmp_gt_u32 vcc, %0, %1")
+OPK32(k_bfi, "v_bfi_b32 %0, %1, %0, %1")
+OPK32(k_and, "v_and_b32 %0, %0, %1")
+OPK32(k_cnd_novcc, "v_cndmask_b32_e64 %0, %0, %1, s[12:13]")
+OPK(k_cmp, "v_cmp_gt_f64 vcc, %0, %1")
+template <typename K>
+static void run_op(const char *name, K kern, double *out, int blocks = 1024) {
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a));
+    CHK(hipEventCreate(&b));
+    const int iters = 20000;
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHK(hipEventRecord(a));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0000001, 0.9999999);
+        CHK(hipEventRecord(b));
+        CHK(hipEventSynchronize(b));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best;
+    }
+    printf("%-22s %d wave(s)/SIMD  %.3f ms  %.2f ns per instruction per SIMD\n", name, blocks / 256, best, best * 1e6 / ((double)blocks * 4 * iters * 32 / 1024.0));
+}
+
 int main() {
     double *out;
     CHK(hipMalloc(&out, 1 << 20));
@@ -97,5 +160,25 @@ int main() {
     for (int w : {1, 2, 4}) run<4>("MFMA f64 16x16x4, four chains, 16 A / B register pairs", w, out);
     for (int w : {1, 2, 4}) run<2>("v_fma_f64, eight independent chains", w, out);
     for (int w : {2, 4}) run<3>("MFMA wavefronts beside v_fma_f64 wavefronts on the same SIMDs", w, out);
+    run_op("v_add_f64", k_add, out);
+    run_op("v_mul_f64", k_mul, out);
+    run_op("v_max_f64", k_max, out);
+    run_op("v_ldexp_f64", k_ldexp, out);
+    run_op("v_rndne_f64", k_rndne, out);
+    run_op("v_rcp_f64", k_rcp, out);
+    run_op("v_frexp_mant_f64", k_frexp, out);
+    run_op("v_mov_b64", k_mov64, out);
+    run_op("v_cndmask_b32", k_cnd, out);
+    run_op("v_add_u32", k_add32, out);
+    run_op("v_cndmask_b32 (vcc)", k_cnd, out, 256);
+    run_op("v_cndmask_b32 (vcc)", k_cnd, out, 512);
+    run_op("v_cndmask_b32_e64 sgpr", k_cnd64, out);
+    run_op("v_cndmask_b32_e64 sgpr", k_cnd64, out, 256);
+    run_op("v_cmp_gt_u32 vcc", k_cmp32, out);
+    run_op("cmp vcc + cndmask vcc", k_cmpcnd, out);
+    run_op("cmp sgpr + cndmask sgpr", k_cmpcnd64, out);
+    run_op("v_bfi_b32", k_bfi, out);
+    run_op("v_and_b32", k_and, out);
+    run_op("v_cmp_gt_f64", k_cmp, out);
     return 0;
 }
