@@ -287,6 +287,7 @@ __global__ void k_op_r_unknown(const double *x, const double *l, int n, DevParam
 // Phase A: AT[t][n] = log p(bin n | theta_t) and V[t][n] = p(bin n | theta_t) (linear domain,
 // r-unknown bins only).  grid = (ceil(Np/256), T_max, n_utr); n is the lane axis.
 // ------------------------------------------------------------------------------------------
+#define PA_TT 8      // theta grid points per workgroup: the bin's data, the UTR descriptor and the exp table are fetched once for all of them
 __global__ __launch_bounds__(256) void k_phase_a(const UtrDesc *__restrict__ descs, DevParams P,
                                                  const double *__restrict__ x,
                                                  const double *__restrict__ l,
@@ -298,28 +299,33 @@ __global__ __launch_bounds__(256) void k_phase_a(const UtrDesc *__restrict__ des
     d_load_exptab(s_exptab, threadIdx.x, blockDim.x);
     __syncthreads();
     const UtrDesc d = descs[blockIdx.z];
-    const int t = blockIdx.y;
+    const int t0 = blockIdx.y * PA_TT, t1 = min(d.T, t0 + PA_TT);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= d.T || n >= d.Np) return;
-    const size_t o = (size_t)d.at_off + (size_t)t * d.Np + n;
+    if (t0 >= d.T || n >= d.Np) return;
     if (n >= d.N) {
-        AT[o] = 0.0;
-        V[o] = 0.0;
+        for (int t = t0; t < t1; ++t) {
+            const size_t o = (size_t)d.at_off + (size_t)t * d.Np + n;
+            AT[o] = 0.0;
+            V[o] = 0.0;
+        }
         return;
     }
-    const double th = theta[d.theta_off + t];
     const double xn = x[d.bin_off + n], ln = l[d.bin_off + n];
     const double rn = r[d.bin_off + n], pan = pa[d.bin_off + n];
-    double a, v = 0.0;
-    if (!isnan(pan)) {
-        a = d_point_pa(xn, ln, pan, th, P.sigma_f);
-    } else if (!isnan(rn)) {
-        a = d_point_r_known(xn, ln, rn, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f);
-    } else {
-        v = d_point_r_unknown(xn, ln, th, P.s_dis, P.pmf_s, P.inv_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
+    for (int t = t0; t < t1; ++t) {
+        const size_t o = (size_t)d.at_off + (size_t)t * d.Np + n;
+        const double th = theta[d.theta_off + t];
+        double a, v = 0.0;
+        if (!isnan(pan)) {
+            a = d_point_pa(xn, ln, pan, th, P.sigma_f);
+        } else if (!isnan(rn)) {
+            a = d_point_r_known(xn, ln, rn, th, P.s_dis, P.pmf_s, P.S, P.mu_f, P.sigma_f);
+        } else {
+            v = d_point_r_unknown(xn, ln, th, P.s_dis, P.pmf_s, P.inv_s, P.S, P.mu_f, P.sigma_f, &a, s_exptab);
+        }
+        AT[o] = a;
+        V[o] = v;
     }
-    AT[o] = a;
-    V[o] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1796,7 +1802,7 @@ int scape_hip_batch_build(scape_hip_ctx *c) {
     if (!c->loaded) return fail("no batch loaded");
     CTX_ENTER(c);
     if (finish_build(c)) return 1;   // a second build on the handle must not wipe the first one's pending flag
-    dim3 grid((c->Np_max + 255) / 256, c->T_max, c->n_utr);
+    dim3 grid((c->Np_max + 255) / 256, (c->T_max + PA_TT - 1) / PA_TT, c->n_utr);
     if (ev_begin(c, 0)) return 1;
     hipLaunchKernelGGL(k_phase_a, grid, dim3(256), 0, c->stream, c->d_desc.as<UtrDesc>(), c->prm, c->d_x.as<double>(),
                        c->d_l.as<double>(), c->d_r.as<double>(), c->d_pa.as<double>(), c->d_theta.as<double>(),
