@@ -308,6 +308,8 @@ class Model:
     # -- EM (apa_core.py:714-779) through the C restatement --
     def em_algo(self, para, fixed=False):
         K = para.K
+        if K > 63:      # the C restatement keeps per-component scratch in 64-entry arrays (a NaN likelihood makes the re-run loop grow K without end)
+            raise RuntimeError(f"oracle: K = {K} is beyond the restatement's 64 columns")
         k_arr = np.ascontiguousarray(gen_k_arr(K, self.nround), dtype=np.int64)
         a = _f64(para.alpha_arr).copy()
         b = _f64(para.beta_arr).copy()

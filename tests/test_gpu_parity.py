@@ -1021,6 +1021,38 @@ def test_beta_step_one_vs_oracle(oracle):
         assert np.allclose(para.ws, want.ws, rtol=1e-8, atol=1e-12) and para.bic == pytest.approx(want.bic, rel=1e-9)
 
 
+def test_random_model_parameters_vs_oracle(oracle):
+    """Every model key of parameters.toml the path reads (ApaModel.__init__, apa_core.py:333-363) drawn at random - theta
+    / beta grids (uniform-grid Phase B with 11- and 12-step windows, the one-kernel form for > 16 beta values), fragment
+    size model, poly(A) length grid, pA gap, pruning thresholds, K range - on small UTRs with pA-site and r-known reads;
+    whole fits (re-run loop on) against the oracle, every field."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    rng = np.random.default_rng(2027)
+    for case in range(10):
+        kw = dict(theta_step=int(rng.choice([5, 7, 9, 12, 15])), beta_step=int(rng.choice([3, 5, 10])),
+                  max_beta=int(rng.choice([40, 55, 70, 90])), n_max_apa=int(rng.integers(2, 7)), n_min_apa=1,
+                  min_ws=float(rng.choice([0.01, 0.05, 0.1])), max_unif_ws=float(rng.choice([0.1, 0.15, 0.3])),
+                  min_pa_gap=int(rng.choice([60, 100, 150])), mu_f=int(rng.choice([250, 300, 350])),
+                  sigma_f=int(rng.choice([40, 50, 65])), min_LA=int(rng.choice([10, 20, 30])),
+                  max_LA=int(rng.choice([150, 180, 200])))     # (>= the synthetic reads' largest r: beyond the s grid the reference's r-known likelihood is NaN)
+        seed = 300 + 10 * case
+        chunk = [synth_utr(i, int(rng.integers(150, 500)), k_cap=4, base_seed=seed, pa_rate=float(rng.choice([0.0, 0.02, 0.2])),
+                           r_rate=float(rng.choice([0.0, 0.05])))[:2] for i in range(3)]
+        preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in chunk]
+        res = Engine(device=0).run(preps, rng_mode="per_utr", seed=seed, re_run_mode=True)
+        for i, ((g, df), r) in enumerate(zip(chunk, res)):
+            np.random.seed(seed + i)
+            want, _m = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, re_run_mode=True, **kw)
+            para = to_parameters(r)
+            assert para.K == want.K and np.array_equal(para.alpha_arr, want.alpha_arr), (case, i, kw)
+            assert np.array_equal(para.beta_arr, want.beta_arr) and np.array_equal(para.label_arr, want.label_arr), (case, i, kw)
+            assert np.allclose(para.ws, want.ws, rtol=1e-6, atol=1e-10) and para.bic == pytest.approx(want.bic, rel=1e-9), (case, i, kw)
+            assert len(para.lb_arr) == len(want.lb_arr), (case, i, kw)
+
+
 def test_phase_b_variants_give_identical_tensors(hip_ctx, monkeypatch):
     """Phase B has three forms: k_phase_b (one kernel: the operator seam, non-uniform theta grids, > 16 beta values),
     tables + per-alpha matrix path (SCAPE_HIP_PHASE_B=split) and - the default on uniform grids - tables + log-bin
