@@ -1053,6 +1053,38 @@ def test_random_model_parameters_vs_oracle(oracle):
             assert len(para.lb_arr) == len(want.lb_arr), (case, i, kw)
 
 
+def test_reference_stream_random_model_parameters_vs_oracle(oracle):
+    """The CLI's default mode - one random stream per chunk (np.random.seed(seed), apa_core.py:125), the UTRs drawing
+    from it one after the other; here several of them per EM call with predicted predecessors (Engine._drive_streams) -
+    under random model parameters: every UTR of the chunk against the oracle run serially on the same stream, and the
+    generator state both leave."""
+    from scape_amd.apa_core import to_parameters
+    from scape_amd.engine import Engine
+    from scape_amd.host import prepare_utr
+    from scape_amd.synth import synth_utr
+    rng = np.random.default_rng(4099)
+    eng = Engine(device=0)
+    for case in range(5):
+        kw = dict(theta_step=int(rng.choice([6, 9, 12])), beta_step=int(rng.choice([5, 10])), max_beta=int(rng.choice([45, 70])),
+                  n_max_apa=int(rng.integers(2, 6)), n_min_apa=1, min_ws=float(rng.choice([0.02, 0.05, 0.1])),
+                  max_unif_ws=float(rng.choice([0.1, 0.15])), min_pa_gap=int(rng.choice([80, 100])))
+        seed = 40 + case
+        chunk = [synth_utr(i, int(rng.integers(150, 450)), k_cap=4, base_seed=900 + 20 * case,
+                           pa_rate=float(rng.choice([0.0, 0.02])))[:2] for i in range(7)]
+        preps = [prepare_utr(df, gene_info_str=g, **kw) for g, df in chunk]
+        rs = np.random.RandomState(seed)
+        res = eng.run(preps, rng_mode="reference", rs=rs, re_run_mode=True)
+        np.random.seed(seed)
+        for i, ((g, df), r) in enumerate(zip(chunk, res)):
+            want, _m = oracle.subsample_run(df["x"].values, df["l"].values, df["r"].values, df["pa"].values, re_run_mode=True, **kw)
+            para = to_parameters(r)
+            assert para.K == want.K and np.array_equal(para.alpha_arr, want.alpha_arr), (case, i, kw)
+            assert np.array_equal(para.beta_arr, want.beta_arr) and np.array_equal(para.label_arr, want.label_arr), (case, i, kw)
+            assert np.allclose(para.ws, want.ws, rtol=1e-6, atol=1e-10) and para.bic == pytest.approx(want.bic, rel=1e-9), (case, i, kw)
+        st, ot = rs.get_state(), np.random.get_state()
+        assert np.array_equal(st[1], ot[1]) and st[2] == ot[2], (case, "generator state after the chunk")
+
+
 def test_phase_b_variants_give_identical_tensors(hip_ctx, monkeypatch):
     """Phase B has three forms: k_phase_b (one kernel: the operator seam, non-uniform theta grids, > 16 beta values),
     tables + per-alpha matrix path (SCAPE_HIP_PHASE_B=split) and - the default on uniform grids - tables + log-bin
