@@ -1,5 +1,5 @@
 #!/bin/bash
-# Phase B time of timing-only builds (results wrong): tools/r3_pb_timing.sh <outdir> <label>=<lib.so> ...
+# Phase A / B time per launch of one or more builds (e.g. timing-only builds, whose results are wrong): tools/r3_pb_timing.sh <outdir> <label>=<lib.so> ...
 set -o pipefail
 OUT=gpurun_out/$1; shift; mkdir -p $OUT
 for arm in "$@"; do
